@@ -1,0 +1,69 @@
+/*
+ * raytracer_c.h -- C ABI over the host-side C++ backend interface (raytracer_amd/libraytracer_amd.so).
+ *
+ * The reference selects a backend by constructing a Renderer subclass in C++ (src/main.cpp:8) and drives it
+ * through the virtual interface of src/scene/Renderer.h:14-42.  This header exposes exactly that interface as
+ * plain C functions so that foreign hosts (ctypes in tests/bench.py, or any FFI) can drive the `hip` backend;
+ * every function names the reference member it forwards to.  Return value: 0, a negative RTHIP_E_* code or a
+ * positive hipError_t (see rthip.h / rthip_error_string).
+ */
+#ifndef RAYTRACER_C_H
+#define RAYTRACER_C_H
+#include <stdint.h>
+#include "rtflat.h"
+#include "rthip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_renderer rt_renderer;
+typedef struct rt_mesh rt_mesh;
+
+/* ---- meshes: what ModelLoader::loadModel returns (src/util/ModelLoader.cpp:8-43) ---- */
+rt_mesh* rt_mesh_cube(void);                                                   /* stand-in for res/models/cube.fbx */
+rt_mesh* rt_mesh_soup(uint32_t numTriangles, uint64_t seed, float edgeRadius); /* BASELINE.md config 3 */
+rt_mesh* rt_mesh_heightfield(uint32_t quadsPerSide, uint64_t seed, float amplitude); /* BASELINE.md config 4/5 */
+rt_mesh* rt_mesh_load_obj(const char* path);                                   /* NULL on failure */
+rt_mesh* rt_mesh_from_arrays(const float* positions, uint32_t numPositions, const float* texCoords, const uint32_t* indices,
+                             uint32_t numTriangles);
+uint32_t rt_mesh_num_positions(const rt_mesh*);
+uint32_t rt_mesh_num_triangles(const rt_mesh*);
+void rt_mesh_copy(const rt_mesh*, float* positions3, uint32_t* indices3);
+void rt_mesh_destroy(rt_mesh*);
+
+/* ---- renderer: Renderer (src/scene/Renderer.h:14-42) with backend "hip" ---- */
+int rt_renderer_create(const char* backend, int device, rt_renderer** out);   /* std::make_unique<...Renderer>(), main.cpp:8 */
+void rt_renderer_destroy(rt_renderer*);
+int rt_add_directional_light(rt_renderer*, const float direction[3], const float color[3]); /* Renderer::addDirectionalLight */
+int rt_add_point_light(rt_renderer*, const float position[3], const float color[3], float attenuation); /* ::addPointLight */
+/* Renderer::addModel(PModel, glm::mat4): the mesh is copied, transform is 16 floats column-major */
+int rt_add_mesh(rt_renderer*, const rt_mesh*, const float transform[16]);
+int rt_generate(rt_renderer*);                                                 /* Renderer::generate */
+
+/* options the reference hard-codes: name in {"maxDepth","aovDepths","tileSize","passesPerCall",
+ * "referenceEdgeIndexing","maxLeafTriangles","sahBins","buildThreads","countWork","kernelTiming"};
+ * scene options must be set before rt_generate */
+int rt_set_option(rt_renderer*, const char* name, double value);
+int rt_set_tiles(rt_renderer*, const uint32_t* tileIds, uint32_t numTiles);    /* tiles this renderer owns; 0 = all */
+
+int rt_start_render(rt_renderer*, const rthip_camera* camera, uint32_t width, uint32_t height, uint32_t numSamples); /* ::startRender */
+int rt_wait_render(rt_renderer*);     /* joins the render thread; returns the render's error code */
+int rt_cancel_render(rt_renderer*);   /* running = false + join (Renderer.cpp:13-17) */
+uint32_t rt_get_sample_times(rt_renderer*, float* msOut, uint32_t cap);        /* ::getSampleTimes */
+int rt_read_accumulator(rt_renderer*, float* rgbOut);                          /* CPURenderer::accumulator */
+int rt_read_image(rt_renderer*, float* rgbOut);                                /* CPURenderer::image */
+int rt_read_aov(rt_renderer*, uint32_t samp, uint32_t depth, uint32_t* triIdOut, uint8_t* shadowOut);
+int rt_get_counters(rt_renderer*, rthip_counters* out);
+int rt_get_kernel_times(rt_renderer*, float msOut[5], uint32_t launchesOut[5]);
+
+/* the flattened scene (valid after rt_generate, owned by the renderer) */
+int rt_get_flat(rt_renderer*, const rtflat_info** info, const rtflat_model_node** modelNodes, const rtflat_node** nodes,
+                const rtflat_tri** tris, double* buildSeconds);
+/* the low-level context, for device-pointer level integration (multi-GPU gather) and probes */
+rthip_ctx* rt_context(rt_renderer*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

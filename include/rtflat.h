@@ -1,0 +1,114 @@
+/*
+ * rtflat.h -- the GPU-friendly scene layout written by the src/scene flattener
+ * (raytracer_amd/src/scene/BvhFlattener.cpp) and consumed by the HIP kernels
+ * (raytracer_amd/csrc) through rthip_upload_scene() (include/rthip.h).
+ *
+ * Every record is exactly 64 bytes and every array is 64-byte aligned, so one
+ * record is one aligned pair of 32-B sectors / half of a 128-B line and a lane
+ * fetches it with four 16-byte loads.
+ *
+ * Reference structures this replaces (citations relative to /root/reference):
+ *   - CPUScene::Node (pointer tree over MODELS)          src/cpu/CPUScene.h:11-19
+ *   - the SoA pools walked by intersectModel/testModel   src/scene/Scene.h:45-51,
+ *                                                        src/cpu/CPUScene.cpp:143-160,191-208
+ *
+ * Three arrays:
+ *   1. rtflat_model_node[]  the reference's model-level tree, SAME topology
+ *      (built by the same pairing loop, src/cpu/CPUScene.cpp:67-105).  Its
+ *      boxes are tested with the reference's exact AABB::intersects arithmetic
+ *      (src/scene/AABB.h:47-60) and both children are always visited.
+ *   2. rtflat_node[]        NEW: a triangle-level BVH2 below each model leaf
+ *      (the reference scans every triangle of a model linearly).  Each node
+ *      stores the boxes of BOTH children, padded outward, so one 64-B fetch
+ *      decides both.  These boxes only ever cull conservatively: they never
+ *      change which triangle the reference's arg-min would pick.
+ *   3. rtflat_tri[]         self-contained triangle records ("Woop-style"
+ *      layout: everything a ray/triangle test needs in one aligned record), in
+ *      BVH leaf order.  The record holds exactly the operands the reference's
+ *      Moeller-Trumbore reads: p0, e0, e1 (src/cpu/CPUScene.cpp:197,205-206) and
+ *      the normalised face normal (:208), not a Woop affine transform, because
+ *      the affine test rounds differently and would flip near-tie winners.
+ */
+#ifndef RTFLAT_H
+#define RTFLAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTFLAT_RECORD_BYTES 64u
+#define RTFLAT_LEAF_BIT 0x80000000u
+#define RTFLAT_MAX_LEAF_TRIS 8u /* count-1 is stored in 3 bits */
+#define RTFLAT_INVALID 0xffffffffu
+
+#if defined(__HIPCC__)
+#define RTFLAT_FN static inline __host__ __device__
+#else
+#define RTFLAT_FN static inline
+#endif
+
+/* child reference: bit31 clear -> index into rtflat_node[];
+ * bit31 set   -> leaf: bits[30:3] = first record in rtflat_tri[], bits[2:0] = count-1 */
+RTFLAT_FN uint32_t rtflat_make_leaf(uint32_t first, uint32_t count)
+{
+  return RTFLAT_LEAF_BIT | (first << 3) | (count - 1u);
+}
+RTFLAT_FN int rtflat_is_leaf(uint32_t ref) { return (ref & RTFLAT_LEAF_BIT) != 0u; }
+RTFLAT_FN uint32_t rtflat_leaf_first(uint32_t ref) { return (ref & 0x7fffffffu) >> 3; }
+RTFLAT_FN uint32_t rtflat_leaf_count(uint32_t ref) { return (ref & 7u) + 1u; }
+
+/* triangle-level BVH2 node: boxes of both children (padded), 64 B */
+typedef struct rtflat_node
+{
+  float lo0[3], hi0[3]; /* child 0 box */
+  float lo1[3], hi1[3]; /* child 1 box */
+  uint32_t child0, child1;
+  uint32_t pad[2];
+} rtflat_node;
+
+/* model-level tree node (reference topology), 64 B */
+typedef struct rtflat_model_node
+{
+  float lo[3], hi[3];  /* Node::aabb, unpadded, tested with the reference's slab arithmetic */
+  uint32_t left, right; /* indices into rtflat_model_node[], RTFLAT_INVALID on a leaf */
+  uint32_t blas;        /* leaf only: child reference into rtflat_node[] / rtflat_tri[] */
+  uint32_t triCount;    /* leaf only: ModelReference::numIndices (0 on inner nodes) */
+  uint32_t indicesOffset; /* leaf only: ModelReference::indicesOffset */
+  uint32_t orderBase;   /* leaf only: first order key of this model (DFS leaf order) */
+  uint32_t modelIndex;  /* leaf only: index of the model in insertion order */
+  uint32_t subtreeSize; /* nodes in this subtree including itself (pre-order skip distance) */
+  uint32_t pad[2];
+} rtflat_model_node;
+
+/* triangle record, 64 B */
+typedef struct rtflat_tri
+{
+  float p0[3]; /* positionPool[positionOffset + idx.x] */
+  float e0[3]; /* edge operand the reference reads for this triangle */
+  float e1[3];
+  float n[3];  /* faceNormalsPool entry (normalised) */
+  uint32_t triId;    /* indicesOffset + posIndex : the hit-id AOV */
+  uint32_t orderKey; /* rank in (DFS leaf order of the model tree, index in model); larger wins ties */
+  uint32_t pad[2];
+} rtflat_tri;
+
+/* scene-wide constants the traversal needs */
+typedef struct rtflat_info
+{
+  uint32_t numModelNodes, numNodes, numTris, rootModelNode;
+  float sceneLo[3], sceneHi[3];
+  float padAbs;      /* absolute outward padding that was applied to every triangle box (before the sliver factor) */
+  float originBound; /* ray origins (camera) must stay within this distance of the scene box centre */
+  float cullRel;     /* closest-hit culling slack: a node is skipped only if entry > best*(1+cullRel)+cullAbs */
+  float cullAbs;
+  uint32_t maxDepthBlas; /* deepest BLAS path (stack bound) */
+  uint32_t numDegenerate; /* triangles whose cross(e0,e1) is exactly zero (outside the parity domain) */
+  uint32_t pad[2];
+} rtflat_info;
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,136 @@
+/*
+ * rthip.h -- the thin C ABI between the host C++ backend (raytracer_amd/src/hip) and the hand-written
+ * gfx950 kernels (raytracer_amd/csrc).  Built into raytracer_amd/librthip.so.
+ *
+ * The reference has no FFI: a backend is a C++ subclass of Renderer/Scene chosen at construction
+ * (src/main.cpp:8).  These entry points are what the reference-side `src/hip/HIPRenderer.cpp` /
+ * `HIPScene.cpp` bind; each cites the reference code whose work it takes over.
+ * Citations are relative to /root/reference.
+ *
+ * Conventions: plain pointers and sizes only; every call returns 0 on success, a negative RTHIP_E_* code for
+ * an argument/state error, or a positive hipError_t; nothing throws across the ABI; all host pointers are
+ * caller-owned and copied from/to before the call returns; a context is bound to one device and may be used
+ * from one host thread at a time (every call sets the device first, because the caller is the
+ * Renderer::worker thread, src/scene/Renderer.cpp:20).
+ */
+#ifndef RTHIP_H
+#define RTHIP_H
+#include <stdint.h>
+#include "rtflat.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTHIP_E_ARG (-1)       /* null pointer / zero size / inconsistent sizes */
+#define RTHIP_E_STATE (-2)     /* call out of order (no scene, no begin) */
+#define RTHIP_E_BOUNDS (-3)    /* camera outside rtflat_info.originBound: box padding would not be conservative */
+#define RTHIP_E_NODEVICE (-4)  /* no usable HIP device */
+#define RTHIP_E_LIMIT (-5)     /* size beyond a compiled-in maximum */
+
+typedef struct rthip_ctx rthip_ctx;
+
+/* same fields as the reference's Camera (src/util/Camera.h:4-12) */
+typedef struct rthip_camera
+{
+  float position[3];
+  float target[3];
+  float sensorSize[2];
+  float S_O, f, A;
+} rthip_camera;
+
+/* 32-byte light records, same layout as src/scene/Scene.h:14-28 */
+typedef struct rthip_point_light
+{
+  float position[3], pad, color[3], attenuation;
+} rthip_point_light;
+typedef struct rthip_dir_light
+{
+  float direction[3], pad, color[3], pad1;
+} rthip_dir_light;
+
+typedef struct rthip_frame_desc
+{
+  uint32_t width, height, numSamples; /* RenderParameter (src/scene/Renderer.h:7-12) */
+  uint32_t maxDepth;                  /* path depth cap; the reference hard-codes 12 (src/cpu/CPUScene.cpp:15) */
+  uint32_t aovDepths;                 /* record hit-id / shadow AOVs for this many depths of each pass (0 = off) */
+  uint32_t tileSize;                  /* square tile edge in pixels (multiple of 8); 0 = default 64 */
+  uint32_t numTiles;                  /* tiles this context renders; 0 = the whole image */
+  uint32_t pad;
+  const uint32_t* tileIds;            /* numTiles tile indices (row-major over ceil(W/ts) x ceil(H/ts)); NULL with numTiles 0 */
+} rthip_frame_desc;
+
+typedef struct rthip_counters
+{
+  uint64_t extendPrimary;   /* closest-hit rays cast at depth 0 */
+  uint64_t extendSecondary; /* closest-hit rays cast at depth >= 1 */
+  uint64_t shadow;          /* any-hit rays cast */
+  uint64_t nodesVisited;    /* 64-B node records fetched (only counted when built with RTHIP_COUNT_WORK or profile mode on) */
+  uint64_t trisTested;
+  uint64_t nonFiniteAccepts;/* triangle tests that passed every rejection with a NaN: outside the parity domain */
+  uint64_t hits[16];        /* closest hits per depth */
+} rthip_counters;
+
+/* creates a context on `device` (a HIP device ordinal); replaces nothing in the reference (it has no device) */
+int rthip_create(int device, rthip_ctx** out);
+int rthip_destroy(rthip_ctx* ctx);
+
+/* Uploads the flattened scene (copies).  Takes over CPUScene::createRayTracingHierarchy's result
+ * (src/cpu/CPUScene.cpp:67-105) and the pools intersectModel reads (src/scene/Scene.h:45-51). */
+int rthip_upload_scene(rthip_ctx* ctx, const rtflat_info* info, const rtflat_model_node* modelNodes, const rtflat_node* nodes,
+                       const rtflat_tri* tris, const rthip_dir_light* dirLights, uint32_t numDirLights,
+                       const rthip_point_light* pointLights, uint32_t numPointLights);
+
+/* Starts a frame: allocates and clears accumulator/image for the tiles of `frame`
+ * (CPURenderer::render's prologue, src/cpu/CPURenderer.cpp:140-143). */
+int rthip_begin(rthip_ctx* ctx, const rthip_camera* camera, const rthip_frame_desc* frame);
+
+/* Renders sample passes [sampBegin, sampBegin+count) : ray generation, <= maxDepth rounds of extend / shade /
+ * shadow, accumulation in `samp` order (the body of the `samp` loop, src/cpu/CPURenderer.cpp:144-206 with
+ * src/cpu/CPUScene.cpp:6-65 inside).  msOut (may be NULL): device time of the whole call in ms, measured with
+ * HIP events on the context's stream. Blocks until the passes are done. */
+int rthip_render_passes(rthip_ctx* ctx, uint32_t sampBegin, uint32_t count, float* msOut);
+/* same, but only enqueues on the context's stream (no host synchronisation, no timing) */
+int rthip_enqueue_passes(rthip_ctx* ctx, uint32_t sampBegin, uint32_t count);
+int rthip_synchronize(rthip_ctx* ctx);
+
+/* Row-major width*height*3 floats (src/cpu/CPURenderer.cpp:197-198 layout); pixels of tiles this context does
+ * not own are left untouched in `out`. */
+int rthip_read_accumulator(rthip_ctx* ctx, float* rgbOut);
+int rthip_read_image(rthip_ctx* ctx, float* rgbOut);
+/* AOVs of sample pass `samp` (must be one of the passes of the LAST render call), depth < aovDepths:
+ * triIdOut[h*width+w] = indicesOffset+posIndex of the closest hit or 0xffffffff; shadowOut bit l = directional
+ * light l occluded, 0xff = no hit.  The reference keeps no ids (HitInfo has none, src/util/Ray.h:19-28). */
+int rthip_read_aov(rthip_ctx* ctx, uint32_t samp, uint32_t depth, uint32_t* triIdOut, uint8_t* shadowOut);
+
+/* Device-side access for the multi-GPU gather: the context's accumulator in its own (tile-major) order.
+ * *devPtr points at numPixels*3 floats; pixel k of local tile j is at ((j*tileSize*tileSize)+k)*3. */
+int rthip_accumulator_device(rthip_ctx* ctx, float** devPtr, uint64_t* numFloats);
+/* scatters a gathered tile-major buffer (device memory, tiles listed in tileIds) into a row-major
+ * width*height*3 device image */
+int rthip_untile(rthip_ctx* ctx, const float* tileMajorDev, const uint32_t* tileIds, uint32_t numTiles, float* rowMajorDev);
+
+int rthip_get_counters(rthip_ctx* ctx, rthip_counters* out); /* totals since rthip_begin */
+/* 1: count nodesVisited/trisTested in the traversal kernels (slower); 0: off (default) */
+int rthip_set_work_counting(rthip_ctx* ctx, int enabled);
+/* per-kernel device milliseconds accumulated since rthip_begin (HIP events around every launch when enabled):
+ * order generate, extend, shade, shadow, accumulate.  enable with rthip_set_kernel_timing(ctx,1). */
+int rthip_set_kernel_timing(rthip_ctx* ctx, int enabled);
+int rthip_get_kernel_times(rthip_ctx* ctx, float msOut[5], uint32_t launchesOut[5]);
+
+/* bit-exactness probes of the device arithmetic against the host (tests only): n inputs each */
+int rthip_probe_rand01(rthip_ctx* ctx, const uint32_t* xyz, uint32_t n, float* out3);
+int rthip_probe_sincos(rthip_ctx* ctx, const float* x, uint32_t n, float* sinOut, float* cosOut);
+int rthip_probe_primary_rays(rthip_ctx* ctx, const rthip_camera* cam, uint32_t width, uint32_t height, const uint32_t* whs,
+                             uint32_t n, float* origin3, float* dir3);
+int rthip_probe_bounce(rthip_ctx* ctx, const float* normalLight3, const float* rnd3, uint32_t n, float* dir3);
+/* closest / any hit of n explicit rays (o,d as 3 floats each) through the uploaded scene */
+int rthip_probe_trace(rthip_ctx* ctx, const float* origin3, const float* dir3, uint32_t n, float tmin, float tmax,
+                      uint32_t* triIdOut, float* tOut, uint8_t* anyOut);
+
+const char* rthip_error_string(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

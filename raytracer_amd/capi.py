@@ -1,0 +1,372 @@
+"""ctypes binding of the product's C ABIs (include/raytracer_c.h, include/rthip.h).
+
+Plumbing only: every call goes straight into libraytracer_amd.so / librthip.so, which are built in-tree by
+`make -C raytracer_amd` (see __graft_entry__.build).  There is no CPU fallback: if the libraries are missing the
+import of this module raises, and a render without a GPU fails with RTHIP_E_NODEVICE.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_HOST = os.path.join(_HERE, "libraytracer_amd.so")
+LIB_HIP = os.path.join(_HERE, "librthip.so")
+
+RTHIP_E_ARG, RTHIP_E_STATE, RTHIP_E_BOUNDS, RTHIP_E_NODEVICE, RTHIP_E_LIMIT = -1, -2, -3, -4, -5
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__(f"{what}: {error_string(code)} ({code})")
+
+
+class Camera(C.Structure):  # rthip_camera == the reference's Camera (src/util/Camera.h:4-12)
+    _fields_ = [("position", C.c_float * 3), ("target", C.c_float * 3), ("sensorSize", C.c_float * 2),
+                ("S_O", C.c_float), ("f", C.c_float), ("A", C.c_float)]
+
+
+class Counters(C.Structure):  # rthip_counters
+    _fields_ = [("extendPrimary", C.c_uint64), ("extendSecondary", C.c_uint64), ("shadow", C.c_uint64),
+                ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64), ("nonFiniteAccepts", C.c_uint64),
+                ("hits", C.c_uint64 * 16)]
+
+    def as_dict(self):
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "hits"}
+        d["hits"] = [int(x) for x in self.hits]
+        return d
+
+
+class FlatInfo(C.Structure):  # rtflat_info
+    _fields_ = [("numModelNodes", C.c_uint32), ("numNodes", C.c_uint32), ("numTris", C.c_uint32), ("rootModelNode", C.c_uint32),
+                ("sceneLo", C.c_float * 3), ("sceneHi", C.c_float * 3), ("padAbs", C.c_float), ("originBound", C.c_float),
+                ("cullRel", C.c_float), ("cullAbs", C.c_float), ("maxDepthBlas", C.c_uint32), ("numDegenerate", C.c_uint32),
+                ("pad", C.c_uint32 * 2)]
+
+
+# numpy views of the 64-byte records of include/rtflat.h
+NODE_DTYPE = np.dtype([("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3), ("child0", "<u4"), ("child1", "<u4"),
+                       ("pad", "<u4", 2)])
+MODEL_NODE_DTYPE = np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("left", "<u4"), ("right", "<u4"), ("blas", "<u4"), ("triCount", "<u4"),
+                             ("indicesOffset", "<u4"), ("orderBase", "<u4"), ("modelIndex", "<u4"), ("subtreeSize", "<u4"),
+                             ("pad", "<u4", 2)])
+TRI_DTYPE = np.dtype([("p0", "<f4", 3), ("e0", "<f4", 3), ("e1", "<f4", 3), ("n", "<f4", 3), ("triId", "<u4"), ("orderKey", "<u4"),
+                      ("pad", "<u4", 2)])
+assert NODE_DTYPE.itemsize == 64 and MODEL_NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 64
+
+_host = None
+_hip = None
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _up(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def hip_lib():
+    global _hip
+    if _hip is None:
+        if not os.path.exists(LIB_HIP):
+            raise ImportError(f"{LIB_HIP} is missing: run `make -C raytracer_amd` (no CPU fallback exists)")
+        L = C.CDLL(LIB_HIP, mode=C.RTLD_GLOBAL)
+        fp, up, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p
+        L.rthip_error_string.restype = C.c_char_p
+        L.rthip_error_string.argtypes = [C.c_int]
+        L.rthip_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.rthip_destroy.argtypes = [vp]
+        L.rthip_probe_rand01.argtypes = [vp, up, C.c_uint32, fp]
+        L.rthip_probe_sincos.argtypes = [vp, fp, C.c_uint32, fp, fp]
+        L.rthip_probe_primary_rays.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, up, C.c_uint32, fp, fp]
+        L.rthip_probe_bounce.argtypes = [vp, fp, fp, C.c_uint32, fp]
+        L.rthip_probe_trace.argtypes = [vp, fp, fp, C.c_uint32, C.c_float, C.c_float, up, fp, C.POINTER(C.c_uint8)]
+        L.rthip_accumulator_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
+        L.rthip_untile.argtypes = [vp, vp, up, C.c_uint32, vp]
+        L.rthip_render_passes.argtypes = [vp, C.c_uint32, C.c_uint32, fp]
+        L.rthip_enqueue_passes.argtypes = [vp, C.c_uint32, C.c_uint32]
+        L.rthip_synchronize.argtypes = [vp]
+        L.rthip_get_counters.argtypes = [vp, C.POINTER(Counters)]
+        L.rthip_get_kernel_times.argtypes = [vp, fp, up]
+        _hip = L
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        hip_lib()
+        if not os.path.exists(LIB_HOST):
+            raise ImportError(f"{LIB_HOST} is missing: run `make -C raytracer_amd` (no CPU fallback exists)")
+        L = C.CDLL(LIB_HOST)
+        fp, up, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p
+        for name in ("rt_mesh_cube", "rt_mesh_soup", "rt_mesh_heightfield", "rt_mesh_load_obj", "rt_mesh_from_arrays", "rt_context"):
+            getattr(L, name).restype = vp
+        L.rt_mesh_soup.argtypes = [C.c_uint32, C.c_uint64, C.c_float]
+        L.rt_mesh_heightfield.argtypes = [C.c_uint32, C.c_uint64, C.c_float]
+        L.rt_mesh_load_obj.argtypes = [C.c_char_p]
+        L.rt_mesh_from_arrays.argtypes = [fp, C.c_uint32, fp, up, C.c_uint32]
+        L.rt_mesh_num_positions.restype = C.c_uint32
+        L.rt_mesh_num_positions.argtypes = [vp]
+        L.rt_mesh_num_triangles.restype = C.c_uint32
+        L.rt_mesh_num_triangles.argtypes = [vp]
+        L.rt_mesh_copy.argtypes = [vp, fp, up]
+        L.rt_mesh_destroy.argtypes = [vp]
+        L.rt_renderer_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+        L.rt_renderer_destroy.argtypes = [vp]
+        L.rt_add_directional_light.argtypes = [vp, fp, fp]
+        L.rt_add_point_light.argtypes = [vp, fp, fp, C.c_float]
+        L.rt_add_mesh.argtypes = [vp, vp, fp]
+        L.rt_generate.argtypes = [vp]
+        L.rt_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+        L.rt_set_tiles.argtypes = [vp, up, C.c_uint32]
+        L.rt_start_render.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32]
+        L.rt_wait_render.argtypes = [vp]
+        L.rt_cancel_render.argtypes = [vp]
+        L.rt_get_sample_times.restype = C.c_uint32
+        L.rt_get_sample_times.argtypes = [vp, fp, C.c_uint32]
+        L.rt_read_accumulator.argtypes = [vp, fp]
+        L.rt_read_image.argtypes = [vp, fp]
+        L.rt_read_aov.argtypes = [vp, C.c_uint32, C.c_uint32, up, C.POINTER(C.c_uint8)]
+        L.rt_get_counters.argtypes = [vp, C.POINTER(Counters)]
+        L.rt_get_kernel_times.argtypes = [vp, fp, up]
+        L.rt_get_flat.argtypes = [vp, C.POINTER(C.POINTER(FlatInfo)), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_double)]
+        L.rt_context.argtypes = [vp]
+        _host = L
+    return _host
+
+
+def error_string(code):
+    return hip_lib().rthip_error_string(int(code)).decode()
+
+
+def _check(code, what):
+    if code != 0:
+        raise RtError(code, what)
+
+
+def make_camera(position, target, S_O=20.0, f=0.7, A=0.35, sensor=(0.036, 0.024)):
+    """Defaults as src/util/Camera.h:8-11; the reference's main.cpp:18-24 uses f=0, A=0, S_O=6."""
+    c = Camera()
+    c.position[:] = [float(x) for x in position]
+    c.target[:] = [float(x) for x in target]
+    c.sensorSize[:] = [float(np.float32(sensor[0])), float(np.float32(sensor[1]))]
+    c.S_O, c.f, c.A = float(S_O), float(f), float(A)
+    return c
+
+
+IDENTITY = np.eye(4, dtype=np.float32)
+
+
+class Mesh:
+    """What ModelLoader::loadModel returns for one aiMesh (src/util/ModelLoader.cpp:14-41)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RtError(RTHIP_E_ARG, "mesh creation")
+        self._h = handle
+
+    @classmethod
+    def cube(cls):
+        return cls(host_lib().rt_mesh_cube())
+
+    @classmethod
+    def soup(cls, num_triangles, seed, edge_radius=0.02):
+        return cls(host_lib().rt_mesh_soup(int(num_triangles), int(seed), float(edge_radius)))
+
+    @classmethod
+    def heightfield(cls, quads_per_side, seed, amplitude=0.15):
+        return cls(host_lib().rt_mesh_heightfield(int(quads_per_side), int(seed), float(amplitude)))
+
+    @classmethod
+    def load_obj(cls, path):
+        return cls(host_lib().rt_mesh_load_obj(os.fsencode(path)))
+
+    @classmethod
+    def from_arrays(cls, positions, indices):
+        p = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        i = np.ascontiguousarray(indices, np.uint32).reshape(-1, 3)
+        return cls(host_lib().rt_mesh_from_arrays(_fp(p), p.shape[0], None, _up(i), i.shape[0]))
+
+    @property
+    def num_positions(self):
+        return host_lib().rt_mesh_num_positions(self._h)
+
+    @property
+    def num_triangles(self):
+        return host_lib().rt_mesh_num_triangles(self._h)
+
+    def arrays(self):
+        p = np.zeros((self.num_positions, 3), np.float32)
+        i = np.zeros((self.num_triangles, 3), np.uint32)
+        host_lib().rt_mesh_copy(self._h, _fp(p), _up(i))
+        return p, i
+
+    def close(self):
+        if self._h:
+            host_lib().rt_mesh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Renderer:
+    """The reference's Renderer interface (src/scene/Renderer.h:14-42) with the `hip` backend behind it."""
+
+    def __init__(self, backend="hip", device=0):
+        h = C.c_void_p()
+        _check(host_lib().rt_renderer_create(backend.encode(), int(device), C.byref(h)), "rt_renderer_create")
+        self._h = h
+        self._size = None
+
+    def close(self):
+        if self._h:
+            host_lib().rt_renderer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_directional_light(self, direction, color=(1, 1, 1)):
+        d, c = np.asarray(direction, np.float32), np.asarray(color, np.float32)
+        _check(host_lib().rt_add_directional_light(self._h, _fp(d), _fp(c)), "rt_add_directional_light")
+
+    def add_point_light(self, position=(0, 0, 0), color=(1, 1, 1), attenuation=1.0):
+        p, c = np.asarray(position, np.float32), np.asarray(color, np.float32)
+        _check(host_lib().rt_add_point_light(self._h, _fp(p), _fp(c), float(attenuation)), "rt_add_point_light")
+
+    def add_mesh(self, mesh, transform=IDENTITY):
+        t = np.ascontiguousarray(np.asarray(transform, np.float32).T)  # glm::mat4 is column-major
+        _check(host_lib().rt_add_mesh(self._h, mesh._h, _fp(t)), "rt_add_mesh")
+
+    def set_option(self, name, value):
+        _check(host_lib().rt_set_option(self._h, name.encode(), float(value)), f"rt_set_option({name})")
+
+    def set_tiles(self, tile_ids):
+        t = np.ascontiguousarray(tile_ids, np.uint32)
+        _check(host_lib().rt_set_tiles(self._h, _up(t), t.size), "rt_set_tiles")
+
+    def generate(self):
+        _check(host_lib().rt_generate(self._h), "rt_generate")
+
+    def start_render(self, camera, width, height, num_samples):
+        self._size = (int(height), int(width))
+        _check(host_lib().rt_start_render(self._h, C.byref(camera), int(width), int(height), int(num_samples)), "rt_start_render")
+
+    def wait(self):
+        _check(host_lib().rt_wait_render(self._h), "render")
+
+    def cancel(self):
+        _check(host_lib().rt_cancel_render(self._h), "rt_cancel_render")
+
+    def render(self, camera, width, height, num_samples):
+        self.start_render(camera, width, height, num_samples)
+        self.wait()
+
+    def sample_times(self):
+        n = host_lib().rt_get_sample_times(self._h, None, 0)
+        out = np.zeros(max(n, 1), np.float32)
+        host_lib().rt_get_sample_times(self._h, _fp(out), n)
+        return out[:n]
+
+    def accumulator(self):
+        h, w = self._size
+        out = np.zeros((h, w, 3), np.float32)
+        _check(host_lib().rt_read_accumulator(self._h, _fp(out)), "rt_read_accumulator")
+        return out
+
+    def image(self):
+        h, w = self._size
+        out = np.zeros((h, w, 3), np.float32)
+        _check(host_lib().rt_read_image(self._h, _fp(out)), "rt_read_image")
+        return out
+
+    def aov(self, samp, depth):
+        h, w = self._size
+        tri = np.full((h, w), 0xFFFFFFFF, np.uint32)
+        sh = np.full((h, w), 0xFF, np.uint8)
+        _check(host_lib().rt_read_aov(self._h, int(samp), int(depth), _up(tri), sh.ctypes.data_as(C.POINTER(C.c_uint8))), "rt_read_aov")
+        return tri, sh
+
+    def counters(self):
+        c = Counters()
+        _check(host_lib().rt_get_counters(self._h, C.byref(c)), "rt_get_counters")
+        return c.as_dict()
+
+    def kernel_times(self):
+        ms = np.zeros(5, np.float32)
+        n = np.zeros(5, np.uint32)
+        _check(host_lib().rt_get_kernel_times(self._h, _fp(ms), _up(n)), "rt_get_kernel_times")
+        names = ("generate", "extend", "shade", "shadow", "accumulate")
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
+
+    def flat(self):
+        """Views (no copy) of the flattened scene: info, model_nodes, nodes, tris, build_seconds."""
+        info = C.POINTER(FlatInfo)()
+        mn, nd, tr = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        secs = C.c_double()
+        _check(host_lib().rt_get_flat(self._h, C.byref(info), C.byref(mn), C.byref(nd), C.byref(tr), C.byref(secs)), "rt_get_flat")
+        i = info.contents
+
+        def view(ptr, count, dtype):
+            buf = (C.c_char * (64 * count)).from_address(ptr.value)
+            return np.frombuffer(buf, dtype=dtype, count=count)
+
+        return dict(info=i, info_bytes=bytes(C.string_at(C.addressof(i), C.sizeof(FlatInfo))),
+                    model_nodes=view(mn, i.numModelNodes, MODEL_NODE_DTYPE), nodes=view(nd, max(i.numNodes, 1), NODE_DTYPE),
+                    tris=view(tr, max(i.numTris, 1), TRI_DTYPE), build_seconds=secs.value)
+
+    @property
+    def context(self):
+        return C.c_void_p(host_lib().rt_context(self._h))
+
+
+class Probe:
+    """Device-arithmetic probes of rthip.h (tests compare them bit for bit with the CPU oracle)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def rand01(self, xyz):
+        a = np.ascontiguousarray(xyz, np.uint32).reshape(-1, 3)
+        out = np.zeros((a.shape[0], 3), np.float32)
+        _check(hip_lib().rthip_probe_rand01(self.ctx, _up(a), a.shape[0], _fp(out)), "rthip_probe_rand01")
+        return out
+
+    def sincos(self, x):
+        a = np.ascontiguousarray(x, np.float32)
+        s, c = np.zeros_like(a), np.zeros_like(a)
+        _check(hip_lib().rthip_probe_sincos(self.ctx, _fp(a), a.size, _fp(s), _fp(c)), "rthip_probe_sincos")
+        return s, c
+
+    def primary_rays(self, camera, width, height, whs):
+        a = np.ascontiguousarray(whs, np.uint32).reshape(-1, 3)
+        o, d = np.zeros((a.shape[0], 3), np.float32), np.zeros((a.shape[0], 3), np.float32)
+        _check(hip_lib().rthip_probe_primary_rays(self.ctx, C.byref(camera), width, height, _up(a), a.shape[0], _fp(o), _fp(d)),
+               "rthip_probe_primary_rays")
+        return o, d
+
+    def bounce(self, normals, rnd):
+        n = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        r = np.ascontiguousarray(rnd, np.float32).reshape(-1, 3)
+        out = np.zeros_like(n)
+        _check(hip_lib().rthip_probe_bounce(self.ctx, _fp(n), _fp(r), n.shape[0], _fp(out)), "rthip_probe_bounce")
+        return out
+
+    def trace(self, origins, dirs, tmin=1e-4, tmax=1e20):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        tri, t, anyh = np.zeros(n, np.uint32), np.zeros(n, np.float32), np.zeros(n, np.uint8)
+        _check(hip_lib().rthip_probe_trace(self.ctx, _fp(o), _fp(d), n, float(np.float32(tmin)), float(np.float32(tmax)), _up(tri), _fp(t),
+                                           anyh.ctypes.data_as(C.POINTER(C.c_uint8))), "rthip_probe_trace")
+        return tri, t, anyh

@@ -1,0 +1,199 @@
+// rt_device.h -- device-side restatement of the reference's per-ray arithmetic (gfx950, wave64).
+// Every function names the reference lines (relative to /root/reference) whose result it must reproduce
+// bit for bit.  Compiled with -ffp-contract=off: an fp32 multiply followed by an add stays two roundings,
+// exactly as on the reference's CPU path; fused multiply-adds appear only where rt::fma is written out.
+#pragma once
+#include "../src/util/Math.h"
+#include "rthip.h"
+#include <cfloat>
+
+namespace rtd
+{
+using rt::vec2;
+using rt::vec3;
+using rt::uvec3;
+
+#define RTD __device__ __forceinline__
+
+// ---- src/cpu/CPURenderer.cpp:111-116
+RTD vec3 rand01(uint32_t x, uint32_t y, uint32_t z)
+{
+#pragma unroll
+  for (int round = 0; round < 3; ++round)
+  {
+    const uint32_t nx = ((x >> 8u) ^ y) * 1103515245u;
+    const uint32_t ny = ((y >> 8u) ^ z) * 1103515245u;
+    const uint32_t nz = ((z >> 8u) ^ x) * 1103515245u;
+    x = nx, y = ny, z = nz;
+  }
+  const float k = 1.0f / float(0xffffffffu); // == 2^-32
+  return vec3{float(x) * k, float(y) * k, float(z) * k};
+}
+
+// Everything of the ray-generation lambda that does not depend on the pixel (CPURenderer.cpp:159-165,178,
+// 182-185,189).  The reference recomputes these per pixel; they are pure functions of the camera, so one
+// device thread computes them once per frame with the same operations.
+struct CameraConsts
+{
+  vec3 origin, direction; // cam
+  vec3 cx, cy;
+  vec3 lc;                // lens centre
+  vec3 lensN, lensX, lensY;
+  vec3 focalPoint;
+  vec2 sdim;
+  float A;
+};
+
+RTD CameraConsts cameraSetup(const rthip_camera& c)
+{
+  CameraConsts k;
+  const vec3 pos{c.position[0], c.position[1], c.position[2]}, tgt{c.target[0], c.target[1], c.target[2]};
+  k.origin = pos;
+  k.direction = rt::normalize(tgt - pos);                                                                 // :159
+  const vec3 up = ((double)fabsf(k.direction.y) < 0.9) ? vec3{0.0f, 1.0f, 0.0f} : vec3{0.0f, 0.0f, 1.0f}; // :161 (double literal)
+  k.cx = rt::normalize(rt::cross(k.direction, up));
+  k.cy = rt::cross(k.cx, k.direction);                                                                    // :162
+  k.sdim = vec2{c.sensorSize[0], c.sensorSize[1]};
+  const float S_I = (c.S_O * c.f) / (c.S_O - c.f);                                                        // :165
+  k.lc = k.origin + k.direction * 0.035f;                                                                 // :178
+  k.lensN = -k.direction;                                                                                 // :183
+  k.lensX = rt::cross(k.lensN, vec3{0.0f, 1.0f, 0.0f});                                                   // :184
+  k.lensY = rt::cross(k.lensN, k.lensX);                                                                  // :185
+  k.focalPoint = k.origin + (c.S_O + S_I) * k.direction;                                                  // :189
+  k.A = c.A;
+  return k;
+}
+
+// ---- CPURenderer.cpp:170-192, the per-(pixel, sample) part
+RTD void primaryRay(const CameraConsts& k, uint32_t width, uint32_t height, uint32_t w, uint32_t h, uint32_t samp, vec3 rnd, vec3& o,
+                    vec3& d)
+{
+  const float r2x = 2.0f * rnd.x, r2y = 2.0f * rnd.y;                                            // :171
+  const float tentx = r2x < 1 ? rt::rt_sqrt(r2x) - 1 : 1 - rt::rt_sqrt(2 - r2x);                 // :172-173
+  const float tenty = r2y < 1 ? rt::rt_sqrt(r2y) - 1 : 1 - rt::rt_sqrt(2 - r2y);
+  const int isamp = (int)samp;
+  const float strx = (float)((isamp / 2) % 2), stry = (float)(isamp % 2);
+  const float sx = (((float)w + 0.5f * ((0.5f + strx) + tentx)) / (float)width - 0.5f) * k.sdim.x; // :174-177
+  const float sy = (((float)h + 0.5f * ((0.5f + stry) + tenty)) / (float)height - 0.5f) * k.sdim.y;
+  const vec3 spos = k.origin + k.cx * sx + k.cy * sy;                                             // :178
+  const vec3 rdir = rt::normalize(k.lc - spos);                                                   // :179 (origin lc)
+  const vec3 lensSample = k.lc + (rnd.x * k.A) * k.lensX + (rnd.y * k.A) * k.lensY;               // :187
+  const float t = rt::dot(k.focalPoint - k.lc, k.lensN) / rt::dot(rdir, k.lensN);                 // :190
+  const vec3 focus = k.lc + t * rdir;                                                             // :191
+  o = lensSample;
+  d = rt::normalize(focus - lensSample);                                                          // :192
+}
+
+// ---- the shared deterministic sin/cos (same algorithm as oracle/rt_math.h sincos_det)
+RTD void sincosDet(float xf, float& s, float& c)
+{
+  const double x = (double)xf;
+  const double TWO_OVER_PI = 0.63661977236758134308;
+  const double PIO2_HI = 1.57079632673412561417e+00;
+  const double PIO2_LO = 6.07710050650619224932e-11;
+  const int q = (int)(x * TWO_OVER_PI + 0.5);
+  const double qd = (double)q;
+  const double y = (x - qd * PIO2_HI) - qd * PIO2_LO;
+  const double z = y * y;
+  double ps = -1.0 / 1307674368000.0;
+  ps = ps * z + 1.0 / 6227020800.0;
+  ps = ps * z - 1.0 / 39916800.0;
+  ps = ps * z + 1.0 / 362880.0;
+  ps = ps * z - 1.0 / 5040.0;
+  ps = ps * z + 1.0 / 120.0;
+  ps = ps * z - 1.0 / 6.0;
+  ps = ps * z + 1.0;
+  const double sy = y * ps;
+  double pc = 1.0 / 20922789888000.0;
+  pc = pc * z - 1.0 / 87178291200.0;
+  pc = pc * z + 1.0 / 479001600.0;
+  pc = pc * z - 1.0 / 3628800.0;
+  pc = pc * z + 1.0 / 40320.0;
+  pc = pc * z - 1.0 / 720.0;
+  pc = pc * z + 1.0 / 24.0;
+  pc = pc * z - 0.5;
+  const double cy = pc * z + 1.0;
+  double sr, cr;
+  switch (q & 3)
+  {
+  case 0: sr = sy; cr = cy; break;
+  case 1: sr = cy; cr = -sy; break;
+  case 2: sr = -sy; cr = -cy; break;
+  default: sr = -cy; cr = sy; break;
+  }
+  s = (float)sr;
+  c = (float)cr;
+}
+
+// ---- src/cpu/CPUScene.cpp:54-60
+RTD vec3 bounceDirection(vec3 normalLight, vec3 rnd)
+{
+  const float r1 = (float)(2 * 3.141592653589793238462643383279502884 * (double)rnd.x);
+  const float r2 = rnd.y;
+  const float r2s = rt::rt_sqrt(r2);
+  const vec3 w = normalLight;
+  const vec3 axis = ((double)fabsf(w.x) > 0.1) ? vec3{0.0f, 1.0f, 0.0f} : vec3{1.0f, 0.0f, 0.0f};
+  const vec3 u = rt::normalize(rt::cross(axis, w));
+  const vec3 v = rt::cross(w, u);
+  float sn, cs;
+  sincosDet(r1, sn, cs);
+  return rt::normalize(u * cs * r2s + v * sn * r2s + w * rt::rt_sqrt(1 - r2));
+}
+
+// ---- src/util/BRDF.cpp:4-14 with the intersector's hard-coded material (CPUScene.cpp:245-246)
+RTD vec3 brdfEvaluate(vec3 albedo, vec3 normal, vec3 lightDir, vec3 lightColor)
+{
+  const float diffuse = rt::maxRef(rt::dot(normal, lightDir), 0.0f);
+  return (albedo * diffuse * lightColor) + vec3{0.03f, 0.03f, 0.03f};
+}
+
+// ---- src/scene/AABB.h:47-60, used for the model-level boxes only
+RTD bool refSlab(const float* lo, const float* hi, vec3 o, vec3 invD, float tmin, float tmax)
+{
+  const vec3 t0{(lo[0] - o.x) * invD.x, (lo[1] - o.y) * invD.y, (lo[2] - o.z) * invD.z};
+  const vec3 t1{(hi[0] - o.x) * invD.x, (hi[1] - o.y) * invD.y, (hi[2] - o.z) * invD.z};
+  const vec3 sm{rt::minRef(t0.x, t1.x), rt::minRef(t0.y, t1.y), rt::minRef(t0.z, t1.z)};
+  const vec3 bg{rt::maxRef(t0.x, t1.x), rt::maxRef(t0.y, t1.y), rt::maxRef(t0.z, t1.z)};
+  tmin = rt::maxRef(tmin, rt::maxRef(sm.x, rt::maxRef(sm.y, sm.z)));
+  tmax = rt::minRef(tmax, rt::minRef(bg.x, rt::minRef(bg.y, bg.z)));
+  return tmin < tmax;
+}
+
+// ---- the triangle test of intersectModel / testModel (CPUScene.cpp:162-181 == :210-229) on a record's
+// operands.  Returns 1 when the reference would keep the triangle, 0 when it `continue`s, 2 when every
+// rejection passed but a value is not finite (outside the parity domain; counted by the caller).
+RTD int triangleTest(vec3 p0, vec3 e0, vec3 e1, vec3 o, vec3 d, float tmin, float tmax, float& tOut)
+{
+  const vec3 s = o - p0;
+  const vec3 s1 = rt::cross(d, e1);
+  const vec3 s2 = rt::cross(s, e0);
+  const float fraction = 1.0f / rt::dot(s1, e0);
+  const float t = rt::dot(s2, e1) * fraction;
+  const float b1 = rt::dot(s1, s) * fraction;
+  const float b2 = rt::dot(s2, d) * fraction;
+  const float b3 = 1.0f - b1 - b2;
+  if (b3 < 0 || b3 > 1)
+    return 0;
+  if (b1 < 0 || b1 > 1)
+    return 0;
+  if (b2 < 0 || b2 > 1)
+    return 0;
+  if (t < tmin || t > tmax)
+    return 0;
+  tOut = t;
+  // accepted by the reference; NaN operands pass every comparison above
+  if (!(fabsf(t) <= FLT_MAX && fabsf(b1) <= FLT_MAX && fabsf(b2) <= FLT_MAX))
+    return 2;
+  return 1;
+}
+
+// ---- conservative slab test for the padded triangle-BVH boxes (no counterpart in the reference)
+RTD void padSlab(vec3 lo, vec3 hi, vec3 invD, vec3 oi, float& entry, float& exit)
+{
+  const float ax = rt::fma(lo.x, invD.x, -oi.x), bx = rt::fma(hi.x, invD.x, -oi.x);
+  const float ay = rt::fma(lo.y, invD.y, -oi.y), by = rt::fma(hi.y, invD.y, -oi.y);
+  const float az = rt::fma(lo.z, invD.z, -oi.z), bz = rt::fma(hi.z, invD.z, -oi.z);
+  entry = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+  exit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+}
+} // namespace rtd

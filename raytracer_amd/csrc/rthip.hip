@@ -1,0 +1,1506 @@
+// rthip.hip -- hand-written gfx950 (CDNA4, wave64) kernels and the C ABI of include/rthip.h.
+//
+// Pipeline of one launch batch (S sample passes x P pixels = S*P paths, slot == path index, nothing moves):
+//   k_generate                      ray generation                       src/cpu/CPURenderer.cpp:158-192
+//   for depth d = 0 .. maxDepth-1
+//     k_trace<SHADOW>  (d > 0)      any-hit toward every directional light from the hit found at depth d-1
+//                                                                        src/cpu/CPUScene.cpp:31-38,107-121,139-186
+//     k_trace<CLOSEST>              closest hit of the depth-d ray       src/cpu/CPUScene.cpp:8,123-137,187-252
+//     k_shade                       fold the lights of depth d-1, roulette, hit set-up, bounce ray
+//                                                                        src/cpu/CPUScene.cpp:10-62
+//   k_trace<SHADOW>, k_shade(final) lights of the last hit
+//   k_accumulate                    accumulator += radiance / N in sample order   src/cpu/CPURenderer.cpp:196-197
+//
+// Traversal kernels are persistent: a fixed grid of waves pulls 512-slot chunks with one atomic each, scans
+// the chunk's liveness bytes, compacts the live slots into a per-wave LDS list with ballot + mbcnt, and keeps
+// its 64 lanes busy by handing the next list entries to lanes whose ray has finished.  Each lane walks the
+// triangle BVH with a short stack in LDS (slot-major, conflict free) that spills to global memory when deeper.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "rt_device.h"
+
+using rt::vec3;
+using rtd::CameraConsts;
+
+#define HIPCHK(x)                                                                                                                \
+  do                                                                                                                            \
+  {                                                                                                                             \
+    hipError_t e_ = (x);                                                                                                        \
+    if (e_ != hipSuccess)                                                                                                       \
+      return (int)e_;                                                                                                           \
+  } while (0)
+
+namespace
+{
+constexpr uint32_t kBlock = 256;       // 4 waves
+constexpr uint32_t kWavesPerBlock = kBlock / 64;
+constexpr uint32_t kChunk = 512;       // slots per work fetch
+constexpr uint32_t kStackLds = 16;     // stack entries per lane kept in LDS
+constexpr uint32_t kSpillCap = 48;     // per-lane spill entries in global memory (stack depth <= kStackLds + kSpillCap)
+constexpr uint32_t kRefillThreshold = 16; // refill once this many lanes are idle (or no lane is active)
+constexpr uint8_t kDead = 0xff;
+constexpr uint32_t kMaxLights = 8;
+constexpr uint32_t kMaxDepthSlots = 64;
+
+enum TraceMode
+{
+  CLOSEST = 0,
+  SHADOW = 1,
+  ANYPROBE = 2
+};
+
+struct DeviceScene
+{
+  const rtflat_model_node* modelNodes;
+  const rtflat_node* nodes;
+  const rtflat_tri* tris;
+  uint32_t numModelNodes;
+  float cullRel, cullAbs;
+};
+
+struct Lights
+{
+  rthip_dir_light dir[kMaxLights];
+  rthip_point_light point[kMaxLights];
+  uint32_t numDir, numPoint;
+};
+
+// device-side tallies; one 64-bit word each, updated once per wave/block at kernel end
+struct DeviceCounters
+{
+  unsigned long long extendPrimary, extendSecondary, shadow, nodesVisited, trisTested, nonFinite;
+  unsigned long long hits[16];
+  unsigned long long alive[kMaxDepthSlots + 2]; // paths alive at each depth of the current batch
+};
+
+struct FrameGeom
+{
+  uint32_t width, height, numSamples;
+  uint32_t tileSize, tilesX, numLocalTiles;
+  uint32_t numLocalPixels; // P
+  const uint32_t* tileIds; // device, numLocalTiles entries
+};
+
+struct PathBuffers
+{
+  float4* rayO;  // o.xyz, w unused
+  float4* rayD;  // d.xyz, w = previous hit's face normal z
+  uint2* hit;    // x = float bits of t, y = triangle record index or RTFLAT_INVALID
+  float4* s0;    // radiance.xyz, material.x
+  float4* s1;    // material.y, material.z, previous normal.x, previous normal.y
+  uint8_t* live; // depth at which the path is waiting, kDead when finished / outside the image
+  uint8_t* mask; // occlusion bits of the previous hit's shadow rays
+};
+
+__device__ __forceinline__ uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t rankIn(uint64_t m)
+{
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// local pixel index -> image pixel; 8x8 pixel blocks are contiguous so a wave covers a compact footprint
+__device__ __forceinline__ bool pixelOf(const FrameGeom& g, uint32_t i, uint32_t& w, uint32_t& h)
+{
+  const uint32_t ts = g.tileSize, per = ts * ts;
+  const uint32_t lt = i / per, k = i - lt * per;
+  const uint32_t tile = g.tileIds ? g.tileIds[lt] : lt;
+  const uint32_t ty = tile / g.tilesX, tx = tile - ty * g.tilesX;
+  const uint32_t blk = k >> 6, l = k & 63u, bpr = ts >> 3;
+  const uint32_t by = blk / bpr, bx = blk - by * bpr;
+  w = tx * ts + bx * 8 + (l & 7u);
+  h = ty * ts + by * 8 + (l >> 3);
+  return w < g.width && h < g.height;
+}
+
+// ------------------------------------------------------------------------------------------------ set-up kernels
+__global__ void k_camera(rthip_camera cam, CameraConsts* out)
+{
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    *out = rtd::cameraSetup(cam);
+}
+
+__global__ __launch_bounds__(kBlock) void k_generate(FrameGeom g, const CameraConsts* camp, PathBuffers pb, uint32_t sampBegin,
+                                                     uint32_t numPaths)
+{
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= numPaths)
+    return;
+  const uint32_t s = p / g.numLocalPixels, i = p - s * g.numLocalPixels;
+  uint32_t w, h;
+  if (!pixelOf(g, i, w, h))
+  {
+    pb.live[p] = kDead;
+    return;
+  }
+  const CameraConsts k = *camp;
+  const uint32_t samp = sampBegin + s;
+  const vec3 rnd = rtd::rand01(w, h, samp);
+  vec3 o, d;
+  rtd::primaryRay(k, g.width, g.height, w, h, samp, rnd, o, d);
+  pb.rayO[p] = make_float4(o.x, o.y, o.z, 0.0f);
+  pb.rayD[p] = make_float4(d.x, d.y, d.z, 0.0f);
+  pb.live[p] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ traversal
+struct TraceArgs
+{
+  DeviceScene scene;
+  PathBuffers pb;
+  Lights* lights;          // SHADOW only
+  uint32_t numSlots;       // S*P
+  uint32_t depth;          // live[] value this launch serves
+  uint32_t* fetchCounter;  // zeroed before the launch
+  uint32_t* spill;         // [kSpillCap][gridLanes]
+  DeviceCounters* counters;
+  float tmin, tmax;
+  // ANYPROBE / probe outputs
+  uint8_t* anyOut;
+};
+
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
+{
+  __shared__ uint32_t sStack[kWavesPerBlock][kStackLds][64];
+  __shared__ uint16_t sList[kWavesPerBlock][kChunk];
+
+  const uint32_t lane = laneId();
+  const uint32_t wv = threadIdx.x >> 6;
+  uint32_t(*stack)[64] = sStack[wv];
+  uint16_t* list = sList[wv];
+  const uint32_t gridLanes = gridDim.x * kBlock;
+  uint32_t* spill = a.spill + (blockIdx.x * kBlock + threadIdx.x);
+
+  const rtflat_model_node* __restrict__ modelNodes = a.scene.modelNodes;
+  const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(a.scene.nodes);
+  const float4* __restrict__ tris4 = reinterpret_cast<const float4*>(a.scene.tris);
+  const uint32_t numModelNodes = a.scene.numModelNodes;
+  const uint32_t numChunks = (a.numSlots + kChunk - 1) / kChunk;
+
+  // wave-uniform work-list state
+  uint32_t chunkBase = 0, listCount = 0, listNext = 0;
+  bool moreChunks = true;
+
+  // per-lane ray state
+  bool active = false;
+  uint32_t slot = 0;
+  vec3 o{0, 0, 0}, d{0, 0, 1}, invD{0, 0, 0}, oi{0, 0, 0};
+  float best = FLT_MAX, cull = FLT_MAX;
+  uint32_t bestRec = RTFLAT_INVALID;
+  uint32_t cur = RTFLAT_INVALID; // inner node index, leaf reference, or RTFLAT_INVALID = "need next model leaf"
+  uint32_t mk = 0;               // model-tree cursor (pre-order index)
+  uint32_t sp = 0, spLo = 0;     // stack entries [spLo, sp) are in LDS, [0, spLo) spilled
+  uint32_t lightIdx = 0;         // SHADOW: which directional light this lane is testing
+  uint32_t occluded = 0;         // SHADOW: result bits
+  unsigned long long nRays = 0, nNodes = 0, nTris = 0;
+
+  for (;;)
+  {
+    // ---------------- work list: fetch + compact the next chunk when the list has run dry
+    const uint64_t idleMask = __ballot(!active);
+    const uint32_t numIdle = __popcll(idleMask);
+    if (listNext >= listCount && moreChunks && (numIdle >= kRefillThreshold))
+    {
+      uint32_t c = 0;
+      if (lane == 0)
+        c = atomicAdd(a.fetchCounter, 1u);
+      c = __builtin_amdgcn_readfirstlane(c);
+      if (c >= numChunks)
+        moreChunks = false;
+      else
+      {
+        chunkBase = c * kChunk;
+        uint32_t n = 0;
+#pragma unroll 4
+        for (uint32_t j = 0; j < kChunk / 64; ++j)
+        {
+          const uint32_t s = chunkBase + j * 64 + lane;
+          const bool isLive = (s < a.numSlots) && (a.pb.live[s] == (uint8_t)a.depth);
+          const uint64_t m = __ballot(isLive);
+          if (isLive)
+            list[n + rankIn(m)] = (uint16_t)(j * 64 + lane);
+          n += __popcll(m);
+        }
+        listCount = n;
+        listNext = 0;
+        // the list is written and read by this wave only; LDS ops of one wave complete in order
+      }
+    }
+    // ---------------- hand list entries to idle lanes
+    const uint32_t avail = listCount - listNext;
+    if (avail > 0 && (numIdle >= kRefillThreshold || numIdle == 64))
+    {
+      const uint32_t r = rankIn(idleMask);
+      const bool take = !active && r < avail;
+      if (take)
+      {
+        slot = chunkBase + list[listNext + r];
+        const float4 ro = a.pb.rayO[slot];
+        o = vec3{ro.x, ro.y, ro.z};
+        if (MODE == SHADOW)
+        {
+          lightIdx = 0;
+          occluded = 0;
+          const rthip_dir_light& L = a.lights->dir[0];
+          d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]}; // Ray(position, -d.direction), CPUScene.cpp:34
+        }
+        else
+        {
+          const float4 rd = a.pb.rayD[slot];
+          d = vec3{rd.x, rd.y, rd.z};
+        }
+        invD = rt::rcp3(d); // AABB.h:49
+        oi = o * invD;
+        best = FLT_MAX;
+        cull = FLT_MAX;
+        bestRec = RTFLAT_INVALID;
+        cur = RTFLAT_INVALID;
+        mk = 0;
+        sp = spLo = 0;
+        active = true;
+        nRays++;
+      }
+      listNext += min(numIdle, avail);
+    }
+    if (__ballot(active) == 0)
+    {
+      if (!moreChunks && listNext >= listCount)
+        break;
+      continue;
+    }
+
+    // ---------------- inner nodes: descend until this lane holds a leaf (or its ray is finished)
+    while (active && ((int)cur >= 0 || cur == RTFLAT_INVALID))
+    {
+      if (cur == RTFLAT_INVALID)
+      {
+        // stack empty: next model leaf whose box chain passes the reference's test, in DFS order
+        // (CPUScene.cpp:123-137 / 107-121: both children always, box test with the caller's tmin/tmax)
+        uint32_t found = RTFLAT_INVALID;
+        while (mk < numModelNodes)
+        {
+          const rtflat_model_node* mn = modelNodes + mk;
+          if (COUNT)
+            nNodes++;
+          if (!rtd::refSlab(mn->lo, mn->hi, o, invD, a.tmin, a.tmax))
+          {
+            mk += mn->subtreeSize; // subtree size: skip it
+            continue;
+          }
+          mk++;
+          if (mn->triCount > 0)
+          {
+            found = mn->blas;
+            break;
+          }
+        }
+        if (found == RTFLAT_INVALID)
+        {
+          // ray finished
+          bool done = true;
+          if (MODE == SHADOW)
+          {
+            // not occluded for this light; next light restarts the walk
+            lightIdx++;
+            if (lightIdx < a.lights->numDir)
+            {
+              const rthip_dir_light& L = a.lights->dir[lightIdx];
+              d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]};
+              invD = rt::rcp3(d);
+              oi = o * invD;
+              mk = 0;
+              nRays++;
+              done = false;
+            }
+            else
+              a.pb.mask[slot] = (uint8_t)occluded;
+          }
+          else if (MODE == CLOSEST)
+            a.pb.hit[slot] = make_uint2(__float_as_uint(best), bestRec);
+          else
+            a.anyOut[slot] = 0;
+          if (done)
+            active = false;
+          continue;
+        }
+        cur = found;
+        continue;
+      }
+      // one 64-byte node: both child boxes
+      const float4* np = nodes4 + (size_t)cur * 4;
+      const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+      if (COUNT)
+        nNodes++;
+      float en0, ex0, en1, ex1;
+      rtd::padSlab(vec3{q0.x, q0.y, q0.z}, vec3{q0.w, q1.x, q1.y}, invD, oi, en0, ex0);
+      rtd::padSlab(vec3{q1.z, q1.w, q2.x}, vec3{q2.y, q2.z, q2.w}, invD, oi, en1, ex1);
+      const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+      const bool h0 = (en0 <= ex0) && (MODE != CLOSEST || en0 <= cull);
+      const bool h1 = (en1 <= ex1) && (MODE != CLOSEST || en1 <= cull);
+      if (h0 && h1)
+      {
+        const bool swap = en1 < en0;
+        const uint32_t farRef = swap ? c0 : c1;
+        cur = swap ? c1 : c0;
+        // push
+        if (sp - spLo == kStackLds)
+        {
+          spill[(size_t)spLo * gridLanes] = stack[spLo % kStackLds][lane];
+          spLo++;
+        }
+        stack[sp % kStackLds][lane] = farRef;
+        sp++;
+      }
+      else if (h0)
+        cur = c0;
+      else if (h1)
+        cur = c1;
+      else
+      {
+        // pop
+        if (sp == 0)
+          cur = RTFLAT_INVALID;
+        else
+        {
+          if (sp == spLo)
+          {
+            spLo--;
+            stack[spLo % kStackLds][lane] = spill[(size_t)spLo * gridLanes];
+          }
+          sp--;
+          cur = stack[sp % kStackLds][lane];
+        }
+      }
+    }
+
+    // ---------------- leaf: the reference's triangle test on every record of the leaf
+    if (active && (int)cur < 0)
+    {
+      const uint32_t first = rtflat_leaf_first(cur), count = rtflat_leaf_count(cur);
+      bool anyAccepted = false;
+      for (uint32_t k = 0; k < count; ++k)
+      {
+        const float4* tp = tris4 + (size_t)(first + k) * 4;
+        const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
+        if (COUNT)
+          nTris++;
+        float t;
+        const int acc = rtd::triangleTest(vec3{a0.x, a0.y, a0.z}, vec3{a0.w, a1.x, a1.y}, vec3{a1.z, a1.w, a2.x}, o, d, a.tmin, a.tmax, t);
+        if (acc == 2)
+          atomicAdd(&a.counters->nonFinite, 1ull);
+        if (acc != 1)
+          continue;
+        if (MODE == CLOSEST)
+        {
+          bool better = t < best;
+          if (!better && t == best)
+          {
+            // tie: the triangle later in (DFS model order, index in model) wins (CPUScene.cpp:231, :136)
+            const uint32_t keyNew = a.scene.tris[first + k].orderKey, keyOld = a.scene.tris[bestRec].orderKey;
+            better = keyNew > keyOld;
+          }
+          if (better)
+          {
+            best = t;
+            bestRec = first + k;
+            cull = rt::fma(best, 1.0f + a.scene.cullRel, a.scene.cullAbs);
+          }
+        }
+        else
+        {
+          anyAccepted = true;
+          break;
+        }
+      }
+      if (MODE != CLOSEST && anyAccepted)
+      {
+        // first accepted triangle ends an any-hit ray (testModel returns true, CPUScene.cpp:182)
+        bool done = true;
+        if (MODE == SHADOW)
+        {
+          occluded |= 1u << lightIdx;
+          lightIdx++;
+          if (lightIdx < a.lights->numDir)
+          {
+            const rthip_dir_light& L = a.lights->dir[lightIdx];
+            d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]};
+            invD = rt::rcp3(d);
+            oi = o * invD;
+            mk = 0;
+            sp = spLo = 0;
+            cur = RTFLAT_INVALID;
+            nRays++;
+            done = false;
+          }
+          else
+            a.pb.mask[slot] = (uint8_t)occluded;
+        }
+        else
+          a.anyOut[slot] = 1;
+        if (done)
+          active = false;
+      }
+      else
+      {
+        // pop
+        if (sp == 0)
+          cur = RTFLAT_INVALID;
+        else
+        {
+          if (sp == spLo)
+          {
+            spLo--;
+            stack[spLo % kStackLds][lane] = spill[(size_t)spLo * gridLanes];
+          }
+          sp--;
+          cur = stack[sp % kStackLds][lane];
+        }
+      }
+    }
+  }
+
+  // ---------------- tallies: one atomic per wave and counter
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    nRays += __shfl_down(nRays, off);
+    if (COUNT)
+    {
+      nNodes += __shfl_down(nNodes, off);
+      nTris += __shfl_down(nTris, off);
+    }
+  }
+  if (lane == 0)
+  {
+    if (nRays)
+    {
+      unsigned long long* dst = (MODE == SHADOW) ? &a.counters->shadow : (a.depth == 0 ? &a.counters->extendPrimary : &a.counters->extendSecondary);
+      atomicAdd(dst, nRays);
+    }
+    if (COUNT && nNodes)
+      atomicAdd(&a.counters->nodesVisited, nNodes);
+    if (COUNT && nTris)
+      atomicAdd(&a.counters->trisTested, nTris);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ shading
+struct ShadeArgs
+{
+  FrameGeom g;
+  DeviceScene scene;
+  PathBuffers pb;
+  const Lights* lights;
+  DeviceCounters* counters;
+  uint32_t numSlots, depth, maxDepth, sampBegin;
+  uint32_t finalFold; // 1: only fold the pending lights and finish every path (depth == maxDepth)
+  uint32_t aovDepths;
+  uint32_t* aovTri;   // [S][aovDepths][P]
+  uint8_t* aovShadow; // [S][aovDepths][P]
+};
+
+__global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
+{
+  __shared__ uint32_t sAlive[kWavesPerBlock], sHits[kWavesPerBlock];
+  uint32_t nAlive = 0, nHits = 0;
+  const uint8_t depthTag = (uint8_t)a.depth;
+  const vec3 albedo{0.0f, 1.0f, 0.0f};    // CPUScene.cpp:245
+  const vec3 emissive{0.0f, 0.0f, 0.0f};  // CPUScene.cpp:246
+  for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < a.numSlots; p += gridDim.x * kBlock)
+  {
+    if (a.pb.live[p] != depthTag)
+      continue;
+    const uint32_t s = p / a.g.numLocalPixels, i = p - s * a.g.numLocalPixels;
+    const float4 ro = a.pb.rayO[p], rd = a.pb.rayD[p];
+    const vec3 o{ro.x, ro.y, ro.z}, d{rd.x, rd.y, rd.z};
+    vec3 radiance{0.0f, 0.0f, 0.0f}, material{1.0f, 1.0f, 1.0f}; // Ray.h:7-8
+    if (a.depth > 0)
+    {
+      const float4 s0 = a.pb.s0[p], s1 = a.pb.s1[p];
+      radiance = vec3{s0.x, s0.y, s0.z};
+      material = vec3{s0.w, s1.x, s1.y};
+      const vec3 nPrev{s1.z, s1.w, rd.w};
+      const uint32_t occl = a.pb.mask[p];
+      // lights of the previous hit, whose position is this ray's origin (CPUScene.cpp:31-49, in that order)
+      for (uint32_t l = 0; l < a.lights->numDir; ++l)
+      {
+        const rthip_dir_light& L = a.lights->dir[l];
+        if (!((occl >> l) & 1u))
+          radiance = radiance + rtd::brdfEvaluate(albedo, nPrev, vec3{-L.direction[0], -L.direction[1], -L.direction[2]},
+                                                  vec3{L.color[0], L.color[1], L.color[2]});
+      }
+      for (uint32_t l = 0; l < a.lights->numPoint; ++l)
+      {
+        const rthip_point_light& L = a.lights->point[l];
+        const vec3 lightDir = vec3{L.position[0], L.position[1], L.position[2]} - o;
+        const float dist = rt::length(lightDir);
+        const float illuminance = rt::maxRef(1 - dist / L.attenuation, 0.0f);
+        radiance = radiance + illuminance * rtd::brdfEvaluate(albedo, nPrev, lightDir, vec3{L.color[0], L.color[1], L.color[2]});
+      }
+      if (a.depth - 1 < a.aovDepths)
+        a.aovShadow[((size_t)s * a.aovDepths + (a.depth - 1)) * a.g.numLocalPixels + i] = (uint8_t)occl;
+    }
+    bool finished = a.finalFold != 0;
+    uint32_t rec = RTFLAT_INVALID;
+    float t = FLT_MAX;
+    vec3 rnd{0, 0, 0};
+    if (!finished)
+    {
+      const uint2 hv = a.pb.hit[p];
+      t = __uint_as_float(hv.x);
+      rec = hv.y;
+      if (!(t < FLT_MAX)) // CPUScene.cpp:10
+        finished = true;
+      else
+      {
+        nHits++;
+        uint32_t w, h;
+        pixelOf(a.g, i, w, h);
+        rnd = rtd::rand01(w, h, a.sampBegin + s);
+        const float pr = rt::maxRef(rt::maxRef(albedo.x, albedo.y), albedo.z); // :13
+        if (a.depth > 5)                                                      // :19 (depth >= maxDepth never reaches here)
+        {
+          if (rnd.z >= pr)
+            finished = true;
+          else
+            material = material / pr;
+        }
+      }
+    }
+    if (finished)
+    {
+      a.pb.s0[p] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+      a.pb.live[p] = kDead;
+      continue;
+    }
+    const float4* tp = reinterpret_cast<const float4*>(a.scene.tris + rec);
+    const float4 a2 = tp[2], a3 = tp[3];
+    const vec3 n{a2.y, a2.z, a2.w};
+    if (a.depth < a.aovDepths)
+      a.aovTri[((size_t)s * a.aovDepths + a.depth) * a.g.numLocalPixels + i] = __float_as_uint(a3.x);
+    const float payloadEmissive = a.depth == 0 ? 1.0f : 0.0f;                  // Ray.h:10, CPUScene.cpp:61
+    radiance = radiance + material * emissive * payloadEmissive;              // :27
+    material = material * albedo;                                             // :28
+    const vec3 position = o + d * t;                                          // :238
+    const vec3 normalLight = rt::dot(n, d) < 0 ? n : -n;                      // :240
+    const vec3 nd = rtd::bounceDirection(normalLight, rnd);                   // :54-60
+    a.pb.rayO[p] = make_float4(position.x, position.y, position.z, 0.0f);
+    a.pb.rayD[p] = make_float4(nd.x, nd.y, nd.z, n.z);
+    a.pb.s0[p] = make_float4(radiance.x, radiance.y, radiance.z, material.x);
+    a.pb.s1[p] = make_float4(material.y, material.z, n.x, n.y);
+    a.pb.live[p] = (uint8_t)(a.depth + 1);
+    nAlive++;
+  }
+  // block tallies: one atomic per block and counter
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    nAlive += __shfl_down(nAlive, off);
+    nHits += __shfl_down(nHits, off);
+  }
+  const uint32_t wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63u) == 0)
+  {
+    sAlive[wv] = nAlive;
+    sHits[wv] = nHits;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    uint32_t ta = 0, th = 0;
+    for (uint32_t k = 0; k < kWavesPerBlock; ++k)
+    {
+      ta += sAlive[k];
+      th += sHits[k];
+    }
+    if (ta)
+      atomicAdd(&a.counters->alive[a.depth + 1], (unsigned long long)ta);
+    if (th)
+      atomicAdd(&a.counters->hits[a.depth < 15 ? a.depth : 15], (unsigned long long)th);
+  }
+}
+
+// accumulator[pix] += radiance / float(N), sample passes in ascending order (CPURenderer.cpp:197)
+__global__ __launch_bounds__(kBlock) void k_accumulate(FrameGeom g, PathBuffers pb, float* acc, uint32_t numBatchSamples)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= g.numLocalPixels)
+    return;
+  if (pb.live[i] != kDead)
+    return; // cannot happen once the pipeline has drained; never add garbage
+  uint32_t w, h;
+  if (!pixelOf(g, i, w, h))
+    return;
+  float r = acc[3 * (size_t)i], gg = acc[3 * (size_t)i + 1], b = acc[3 * (size_t)i + 2];
+  const float n = float(g.numSamples);
+  for (uint32_t s = 0; s < numBatchSamples; ++s)
+  {
+    const float4 v = pb.s0[(size_t)s * g.numLocalPixels + i];
+    r += v.x / n;
+    gg += v.y / n;
+    b += v.z / n;
+  }
+  acc[3 * (size_t)i] = r;
+  acc[3 * (size_t)i + 1] = gg;
+  acc[3 * (size_t)i + 2] = b;
+}
+
+// image = pow(max(accumulator * resolver, 0), 0.45)  (CPURenderer.cpp:196,198); display only
+__global__ __launch_bounds__(kBlock) void k_tonemap(const float* acc, float* img, uint32_t numFloats, float resolver)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < numFloats)
+    img[i] = powf(rt::maxRef(acc[i] * resolver, 0.0f), 0.45f);
+}
+
+// tile-major -> row-major scatter (multi-GPU assembly and read-back)
+__global__ __launch_bounds__(kBlock) void k_untile(FrameGeom g, const float* tileMajor, float* rowMajor, uint32_t numPixels)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= numPixels)
+    return;
+  uint32_t w, h;
+  if (!pixelOf(g, i, w, h))
+    return;
+  const size_t dst = 3 * ((size_t)h * g.width + w);
+  rowMajor[dst] = tileMajor[3 * (size_t)i];
+  rowMajor[dst + 1] = tileMajor[3 * (size_t)i + 1];
+  rowMajor[dst + 2] = tileMajor[3 * (size_t)i + 2];
+}
+
+// ------------------------------------------------------------------------------------------------ probes
+__global__ void k_probe_rand01(const uint32_t* xyz, uint32_t n, float* out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const vec3 r = rtd::rand01(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+  out[3 * i] = r.x, out[3 * i + 1] = r.y, out[3 * i + 2] = r.z;
+}
+__global__ void k_probe_sincos(const float* x, uint32_t n, float* s, float* c)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    rtd::sincosDet(x[i], s[i], c[i]);
+}
+__global__ void k_probe_rays(const CameraConsts* camp, uint32_t width, uint32_t height, const uint32_t* whs, uint32_t n, float* o3, float* d3)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const CameraConsts k = *camp;
+  const uint32_t w = whs[3 * i], h = whs[3 * i + 1], s = whs[3 * i + 2];
+  vec3 o, d;
+  rtd::primaryRay(k, width, height, w, h, s, rtd::rand01(w, h, s), o, d);
+  o3[3 * i] = o.x, o3[3 * i + 1] = o.y, o3[3 * i + 2] = o.z;
+  d3[3 * i] = d.x, d3[3 * i + 1] = d.y, d3[3 * i + 2] = d.z;
+}
+__global__ void k_probe_bounce(const float* n3, const float* r3, uint32_t n, float* d3)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const vec3 d = rtd::bounceDirection(vec3{n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]}, vec3{r3[3 * i], r3[3 * i + 1], r3[3 * i + 2]});
+  d3[3 * i] = d.x, d3[3 * i + 1] = d.y, d3[3 * i + 2] = d.z;
+}
+__global__ void k_probe_pack(const float* o3, const float* d3, uint32_t n, float4* ro, float4* rd, uint8_t* live)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  ro[i] = make_float4(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2], 0.0f);
+  rd[i] = make_float4(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2], 0.0f);
+  live[i] = 0;
+}
+__global__ void k_probe_unpack(const DeviceScene scene, const uint2* hit, uint32_t n, uint32_t* triId, float* t)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const uint2 h = hit[i];
+  t[i] = __uint_as_float(h.x);
+  triId[i] = (h.y == RTFLAT_INVALID) ? RTFLAT_INVALID : scene.tris[h.y].triId;
+}
+
+template <typename T>
+struct DevBuf
+{
+  T* p = nullptr;
+  size_t n = 0;
+  int ensure(size_t count)
+  {
+    if (count <= n && p)
+      return 0;
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    HIPCHK(hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)));
+    n = count;
+    return 0;
+  }
+  void release()
+  {
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+} // namespace
+
+struct rthip_ctx
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t evA = nullptr, evB = nullptr, evK0 = nullptr, evK1 = nullptr;
+  int numCUs = 256;
+  uint32_t traceBlocks = 2048;
+  // scene
+  bool haveScene = false;
+  rtflat_info info{};
+  DevBuf<rtflat_model_node> modelNodes;
+  DevBuf<rtflat_node> nodes;
+  DevBuf<rtflat_tri> tris;
+  DevBuf<Lights> lights;
+  Lights hostLights{};
+  // frame
+  bool haveFrame = false;
+  rthip_camera camera{};
+  FrameGeom geom{};
+  uint32_t maxDepth = 12, aovDepths = 0;
+  uint32_t batchCap = 1; // sample passes per launch batch
+  std::vector<uint32_t> hostTileIds;
+  DevBuf<uint32_t> tileIds;
+  DevBuf<CameraConsts> camConsts;
+  DevBuf<float4> rayO, rayD, s0, s1;
+  DevBuf<uint2> hit;
+  DevBuf<uint8_t> live, mask, anyOut;
+  DevBuf<float> acc, img, rowScratch;
+  DevBuf<uint32_t> aovTri;
+  DevBuf<uint8_t> aovShadow;
+  DevBuf<uint32_t> fetch; // one work-fetch counter per traversal launch of a batch
+  DevBuf<uint32_t> spill;
+  DevBuf<DeviceCounters> counters;
+  uint32_t lastBatchBegin = 0, lastBatchCount = 0, lastSamp = 0;
+  bool renderedAny = false;
+  bool countWork = false, kernelTiming = false;
+  float kernelMs[5] = {};
+  uint32_t kernelLaunches[5] = {};
+  rthip_counters totals{};
+};
+
+namespace
+{
+DeviceScene devScene(const rthip_ctx* c)
+{
+  DeviceScene s;
+  s.modelNodes = c->modelNodes.p;
+  s.nodes = c->nodes.p;
+  s.tris = c->tris.p;
+  s.numModelNodes = c->info.numModelNodes;
+  s.cullRel = c->info.cullRel;
+  s.cullAbs = c->info.cullAbs;
+  return s;
+}
+PathBuffers pathBuffers(const rthip_ctx* c)
+{
+  PathBuffers pb;
+  pb.rayO = c->rayO.p, pb.rayD = c->rayD.p, pb.hit = c->hit.p, pb.s0 = c->s0.p, pb.s1 = c->s1.p, pb.live = c->live.p, pb.mask = c->mask.p;
+  return pb;
+}
+
+struct KernelTimer
+{
+  rthip_ctx* c;
+  int which;
+  KernelTimer(rthip_ctx* ctx, int k) : c(ctx), which(k)
+  {
+    if (c->kernelTiming)
+      (void)hipEventRecord(c->evK0, c->stream);
+  }
+  ~KernelTimer()
+  {
+    c->kernelLaunches[which]++;
+    if (c->kernelTiming)
+    {
+      (void)hipEventRecord(c->evK1, c->stream);
+      (void)hipEventSynchronize(c->evK1);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, c->evK0, c->evK1);
+      c->kernelMs[which] += ms;
+    }
+  }
+};
+
+int ensurePathBuffers(rthip_ctx* c, size_t numSlots)
+{
+  int rc;
+  if ((rc = c->rayO.ensure(numSlots)) || (rc = c->rayD.ensure(numSlots)) || (rc = c->s0.ensure(numSlots)) || (rc = c->s1.ensure(numSlots)) ||
+      (rc = c->hit.ensure(numSlots)) || (rc = c->live.ensure(numSlots + 64)) || (rc = c->mask.ensure(numSlots)))
+    return rc;
+  if ((rc = c->spill.ensure((size_t)kSpillCap * c->traceBlocks * kBlock)))
+    return rc;
+  if ((rc = c->fetch.ensure(2 * kMaxDepthSlots + 8)))
+    return rc;
+  return c->counters.ensure(1);
+}
+
+template <int MODE>
+int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t fetchIndex, float tmin, float tmax)
+{
+  TraceArgs a;
+  a.scene = devScene(c);
+  a.pb = pathBuffers(c);
+  a.lights = c->lights.p;
+  a.numSlots = numSlots;
+  a.depth = depth;
+  a.fetchCounter = c->fetch.p + fetchIndex;
+  a.spill = c->spill.p;
+  a.counters = c->counters.p;
+  a.tmin = tmin;
+  a.tmax = tmax;
+  a.anyOut = c->anyOut.p;
+  const uint32_t chunks = (numSlots + kChunk - 1) / kChunk;
+  const uint32_t blocks = std::max(1u, std::min(c->traceBlocks, (chunks + kWavesPerBlock - 1) / kWavesPerBlock));
+  KernelTimer kt(c, MODE == CLOSEST ? 1 : 3);
+  if (c->countWork)
+    hipLaunchKernelGGL((k_trace<MODE, true>), dim3(blocks), dim3(kBlock), 0, c->stream, a);
+  else
+    hipLaunchKernelGGL((k_trace<MODE, false>), dim3(blocks), dim3(kBlock), 0, c->stream, a);
+  return (int)hipGetLastError();
+}
+
+void addCounters(rthip_counters& dst, const DeviceCounters& s)
+{
+  dst.extendPrimary += s.extendPrimary;
+  dst.extendSecondary += s.extendSecondary;
+  dst.shadow += s.shadow;
+  dst.nodesVisited += s.nodesVisited;
+  dst.trisTested += s.trisTested;
+  dst.nonFiniteAccepts += s.nonFinite;
+  for (int i = 0; i < 16; ++i)
+    dst.hits[i] += s.hits[i];
+}
+
+// one batch of `count` sample passes starting at sampBegin
+int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, bool allowHostPolls)
+{
+  const uint32_t P = c->geom.numLocalPixels;
+  const uint32_t numSlots = P * count;
+  const uint32_t shadeBlocks = std::max(1u, std::min((numSlots + kBlock - 1) / kBlock, (uint32_t)c->numCUs * 8u));
+  HIPCHK(hipMemsetAsync(c->fetch.p, 0, c->fetch.n * sizeof(uint32_t), c->stream));
+  HIPCHK(hipMemsetAsync(c->counters.p, 0, sizeof(DeviceCounters), c->stream));
+  if (c->aovDepths)
+  {
+    HIPCHK(hipMemsetAsync(c->aovTri.p, 0xff, (size_t)count * c->aovDepths * P * sizeof(uint32_t), c->stream));
+    HIPCHK(hipMemsetAsync(c->aovShadow.p, 0xff, (size_t)count * c->aovDepths * P, c->stream));
+  }
+  {
+    KernelTimer kt(c, 0);
+    hipLaunchKernelGGL(k_generate, dim3((numSlots + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->geom, c->camConsts.p, pathBuffers(c),
+                       sampBegin, numSlots);
+    HIPCHK(hipGetLastError());
+  }
+  const bool haveDirLights = c->hostLights.numDir > 0;
+  uint32_t fetchIndex = 0;
+  ShadeArgs sa;
+  sa.g = c->geom;
+  sa.scene = devScene(c);
+  sa.pb = pathBuffers(c);
+  sa.lights = c->lights.p;
+  sa.counters = c->counters.p;
+  sa.numSlots = numSlots;
+  sa.maxDepth = c->maxDepth;
+  sa.sampBegin = sampBegin;
+  sa.aovDepths = c->aovDepths;
+  sa.aovTri = c->aovTri.p;
+  sa.aovShadow = c->aovShadow.p;
+  const float tmin = 1e-4f, tmax = 1e20f; // CPURenderer.cpp:194, CPUScene.cpp:34 (double literals narrowed to float)
+  uint32_t d = 0;
+  for (;; ++d)
+  {
+    const bool last = d == c->maxDepth;
+    if (d > 0 && haveDirLights)
+    {
+      int rc = launchTrace<SHADOW>(c, numSlots, d, fetchIndex++, tmin, tmax);
+      if (rc)
+        return rc;
+    }
+    else if (d > 0)
+      HIPCHK(hipMemsetAsync(c->mask.p, 0, numSlots, c->stream));
+    if (!last)
+    {
+      int rc = launchTrace<CLOSEST>(c, numSlots, d, fetchIndex++, tmin, tmax);
+      if (rc)
+        return rc;
+    }
+    sa.depth = d;
+    sa.finalFold = last ? 1u : 0u;
+    {
+      KernelTimer kt(c, 2);
+      hipLaunchKernelGGL(k_shade, dim3(shadeBlocks), dim3(kBlock), 0, c->stream, sa);
+      HIPCHK(hipGetLastError());
+    }
+    if (last)
+      break;
+    if (allowHostPolls && d >= 1)
+    {
+      // stop issuing depths once no path is alive (paths end by miss long before the cap in open scenes)
+      unsigned long long alive = 0;
+      HIPCHK(hipMemcpyAsync(&alive, &c->counters.p->alive[d + 1], sizeof(alive), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (alive == 0)
+        break;
+    }
+  }
+  {
+    KernelTimer kt(c, 4);
+    hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->geom, pathBuffers(c), c->acc.p, count);
+    HIPCHK(hipGetLastError());
+  }
+  c->lastBatchBegin = sampBegin;
+  c->lastBatchCount = count;
+  c->lastSamp = sampBegin + count - 1;
+  c->renderedAny = true;
+  return 0;
+}
+
+int foldCounters(rthip_ctx* c)
+{
+  DeviceCounters dc;
+  HIPCHK(hipMemcpyAsync(&dc, c->counters.p, sizeof(dc), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  addCounters(c->totals, dc);
+  return 0;
+}
+
+int renderPasses(rthip_ctx* c, uint32_t sampBegin, uint32_t count, bool sync)
+{
+  if (!c->haveScene || !c->haveFrame)
+    return RTHIP_E_STATE;
+  if (count == 0 || sampBegin + count > c->geom.numSamples)
+    return RTHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  uint32_t done = 0;
+  while (done < count)
+  {
+    const uint32_t n = std::min(c->batchCap, count - done);
+    int rc = renderBatch(c, sampBegin + done, n, true);
+    if (rc)
+      return rc;
+    rc = foldCounters(c); // also drains the batch so its path buffers can be reused
+    if (rc)
+      return rc;
+    done += n;
+  }
+  if (sync)
+    HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+} // namespace
+
+extern "C" {
+
+const char* rthip_error_string(int code)
+{
+  switch (code)
+  {
+  case 0: return "success";
+  case RTHIP_E_ARG: return "rthip: invalid argument";
+  case RTHIP_E_STATE: return "rthip: call out of order (scene or frame missing)";
+  case RTHIP_E_BOUNDS: return "rthip: camera outside the origin bound the scene was flattened for";
+  case RTHIP_E_NODEVICE: return "rthip: no usable HIP device";
+  case RTHIP_E_LIMIT: return "rthip: size beyond a compiled-in limit";
+  default: return code > 0 ? hipGetErrorString((hipError_t)code) : "rthip: unknown error";
+  }
+}
+
+int rthip_create(int device, rthip_ctx** out)
+{
+  if (!out)
+    return RTHIP_E_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+    return RTHIP_E_NODEVICE;
+  HIPCHK(hipSetDevice(device));
+  rthip_ctx* c = new (std::nothrow) rthip_ctx();
+  if (!c)
+    return RTHIP_E_ARG;
+  c->device = device;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  c->traceBlocks = (uint32_t)c->numCUs * 8u; // 8 blocks x 4 waves = 32 waves per CU when registers allow
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&c->evA));
+  HIPCHK(hipEventCreate(&c->evB));
+  HIPCHK(hipEventCreate(&c->evK0));
+  HIPCHK(hipEventCreate(&c->evK1));
+  *out = c;
+  return 0;
+}
+
+int rthip_destroy(rthip_ctx* c)
+{
+  if (!c)
+    return RTHIP_E_ARG;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  c->modelNodes.release(), c->nodes.release(), c->tris.release(), c->lights.release(), c->tileIds.release(), c->camConsts.release();
+  c->rayO.release(), c->rayD.release(), c->s0.release(), c->s1.release(), c->hit.release(), c->live.release(), c->mask.release();
+  c->anyOut.release(), c->acc.release(), c->img.release(), c->rowScratch.release(), c->aovTri.release(), c->aovShadow.release();
+  c->fetch.release(), c->spill.release(), c->counters.release();
+  (void)hipEventDestroy(c->evA), (void)hipEventDestroy(c->evB), (void)hipEventDestroy(c->evK0), (void)hipEventDestroy(c->evK1);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+int rthip_upload_scene(rthip_ctx* c, const rtflat_info* info, const rtflat_model_node* modelNodes, const rtflat_node* nodes,
+                       const rtflat_tri* tris, const rthip_dir_light* dirLights, uint32_t numDirLights,
+                       const rthip_point_light* pointLights, uint32_t numPointLights)
+{
+  if (!c || !info || !modelNodes || !nodes || !tris || (numDirLights && !dirLights) || (numPointLights && !pointLights))
+    return RTHIP_E_ARG;
+  if (info->numModelNodes == 0 || info->numTris == 0 || info->numNodes == 0)
+    return RTHIP_E_ARG;
+  if (numDirLights > kMaxLights || numPointLights > kMaxLights || info->numTris >= (1u << 28) - 1u)
+    return RTHIP_E_LIMIT;
+  // the per-lane stack must hold the deepest root-to-leaf chain of far children
+  if (info->maxDepthBlas + 2 > kStackLds + kSpillCap)
+    return RTHIP_E_LIMIT;
+  // host-side shape checks before any kernel dereferences these indices
+  for (uint32_t k = 0; k < info->numModelNodes; ++k)
+  {
+    const rtflat_model_node& mn = modelNodes[k];
+    if (mn.subtreeSize == 0 || k + mn.subtreeSize > info->numModelNodes)
+      return RTHIP_E_ARG;
+    if (mn.triCount > 0)
+    {
+      const uint32_t ref = mn.blas;
+      if (rtflat_is_leaf(ref) ? (rtflat_leaf_first(ref) + rtflat_leaf_count(ref) > info->numTris) : (ref >= info->numNodes))
+        return RTHIP_E_ARG;
+    }
+  }
+  for (uint32_t k = 0; k < info->numNodes; ++k)
+  {
+    if (info->numNodes == 1 && nodes[k].child0 == 0 && nodes[k].child1 == 0)
+      break; // placeholder node of a scene whose models are all single leaves
+    for (uint32_t ref : {nodes[k].child0, nodes[k].child1})
+      if (rtflat_is_leaf(ref) ? (rtflat_leaf_first(ref) + rtflat_leaf_count(ref) > info->numTris) : (ref >= info->numNodes || ref <= k))
+        return RTHIP_E_ARG; // children follow their parent (pre-order): no cycles
+  }
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int rc;
+  if ((rc = c->modelNodes.ensure(info->numModelNodes)) || (rc = c->nodes.ensure(info->numNodes)) || (rc = c->tris.ensure(info->numTris)) ||
+      (rc = c->lights.ensure(1)))
+    return rc;
+  HIPCHK(hipMemcpy(c->modelNodes.p, modelNodes, sizeof(rtflat_model_node) * info->numModelNodes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->nodes.p, nodes, sizeof(rtflat_node) * info->numNodes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->tris.p, tris, sizeof(rtflat_tri) * info->numTris, hipMemcpyHostToDevice));
+  Lights& L = c->hostLights;
+  std::memset(&L, 0, sizeof(L));
+  L.numDir = numDirLights;
+  L.numPoint = numPointLights;
+  for (uint32_t i = 0; i < numDirLights; ++i)
+    L.dir[i] = dirLights[i];
+  for (uint32_t i = 0; i < numPointLights; ++i)
+    L.point[i] = pointLights[i];
+  HIPCHK(hipMemcpy(c->lights.p, &L, sizeof(L), hipMemcpyHostToDevice));
+  c->info = *info;
+  c->haveScene = true;
+  c->haveFrame = false;
+  return 0;
+}
+
+int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc* f)
+{
+  if (!c || !camera || !f || f->width == 0 || f->height == 0 || f->numSamples == 0)
+    return RTHIP_E_ARG;
+  if (!c->haveScene)
+    return RTHIP_E_STATE;
+  if (f->maxDepth == 0 || f->maxDepth > kMaxDepthSlots || f->maxDepth > 254)
+    return RTHIP_E_LIMIT;
+  const uint32_t ts = f->tileSize ? f->tileSize : 64u;
+  if (ts % 8u)
+    return RTHIP_E_ARG;
+  // the padding of the BVH boxes was sized for ray origins within originBound of the scene centre
+  {
+    float d2 = 0;
+    for (int k = 0; k < 3; ++k)
+    {
+      const float ctr = 0.5f * (c->info.sceneLo[k] + c->info.sceneHi[k]);
+      d2 += (camera->position[k] - ctr) * (camera->position[k] - ctr);
+    }
+    if (!(d2 <= c->info.originBound * c->info.originBound))
+      return RTHIP_E_BOUNDS;
+  }
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const uint32_t tilesX = (f->width + ts - 1) / ts, tilesY = (f->height + ts - 1) / ts;
+  FrameGeom g{};
+  g.width = f->width, g.height = f->height, g.numSamples = f->numSamples;
+  g.tileSize = ts, g.tilesX = tilesX;
+  c->hostTileIds.clear();
+  if (f->numTiles)
+  {
+    if (!f->tileIds)
+      return RTHIP_E_ARG;
+    for (uint32_t k = 0; k < f->numTiles; ++k)
+    {
+      if (f->tileIds[k] >= tilesX * tilesY)
+        return RTHIP_E_ARG;
+      c->hostTileIds.push_back(f->tileIds[k]);
+    }
+  }
+  else
+    for (uint32_t k = 0; k < tilesX * tilesY; ++k)
+      c->hostTileIds.push_back(k);
+  g.numLocalTiles = (uint32_t)c->hostTileIds.size();
+  const uint64_t P64 = (uint64_t)g.numLocalTiles * ts * ts;
+  if (P64 == 0 || P64 > (1ull << 30))
+    return RTHIP_E_LIMIT;
+  g.numLocalPixels = (uint32_t)P64;
+  int rc;
+  if ((rc = c->tileIds.ensure(g.numLocalTiles)))
+    return rc;
+  HIPCHK(hipMemcpy(c->tileIds.p, c->hostTileIds.data(), sizeof(uint32_t) * g.numLocalTiles, hipMemcpyHostToDevice));
+  g.tileIds = c->tileIds.p;
+  c->geom = g;
+  c->camera = *camera;
+  c->maxDepth = f->maxDepth;
+  c->aovDepths = std::min(f->aovDepths, f->maxDepth);
+  // sample passes per launch batch: as many as fit in 2^25 paths (about 90 B of state each)
+  const uint64_t pathCap = 1ull << 25;
+  c->batchCap = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(f->numSamples, pathCap / P64));
+  if (c->aovDepths)
+    c->batchCap = std::min(c->batchCap, 4u);
+  const size_t numSlots = (size_t)P64 * c->batchCap;
+  if ((rc = ensurePathBuffers(c, numSlots)) || (rc = c->acc.ensure(P64 * 3)) || (rc = c->img.ensure(P64 * 3)) || (rc = c->camConsts.ensure(1)))
+    return rc;
+  if (c->aovDepths)
+  {
+    if ((rc = c->aovTri.ensure(numSlots * c->aovDepths)) || (rc = c->aovShadow.ensure(numSlots * c->aovDepths)))
+      return rc;
+  }
+  HIPCHK(hipMemsetAsync(c->acc.p, 0, P64 * 3 * sizeof(float), c->stream));
+  HIPCHK(hipMemsetAsync(c->img.p, 0, P64 * 3 * sizeof(float), c->stream));
+  hipLaunchKernelGGL(k_camera, dim3(1), dim3(64), 0, c->stream, *camera, c->camConsts.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::memset(&c->totals, 0, sizeof(c->totals));
+  std::memset(c->kernelMs, 0, sizeof(c->kernelMs));
+  std::memset(c->kernelLaunches, 0, sizeof(c->kernelLaunches));
+  c->renderedAny = false;
+  c->haveFrame = true;
+  return 0;
+}
+
+int rthip_render_passes(rthip_ctx* c, uint32_t sampBegin, uint32_t count, float* msOut)
+{
+  if (!c)
+    return RTHIP_E_ARG;
+  if (!c->haveScene || !c->haveFrame)
+    return RTHIP_E_STATE;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipEventRecord(c->evA, c->stream));
+  int rc = renderPasses(c, sampBegin, count, false);
+  if (rc)
+    return rc;
+  HIPCHK(hipEventRecord(c->evB, c->stream));
+  HIPCHK(hipEventSynchronize(c->evB));
+  if (msOut)
+    HIPCHK(hipEventElapsedTime(msOut, c->evA, c->evB));
+  return 0;
+}
+
+int rthip_enqueue_passes(rthip_ctx* c, uint32_t sampBegin, uint32_t count)
+{
+  if (!c)
+    return RTHIP_E_ARG;
+  return renderPasses(c, sampBegin, count, false);
+}
+
+int rthip_synchronize(rthip_ctx* c)
+{
+  if (!c)
+    return RTHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int readTiled(rthip_ctx* c, const float* tileMajorDev, float* rgbOut)
+{
+  const size_t full = (size_t)c->geom.width * c->geom.height * 3;
+  int rc = c->rowScratch.ensure(full);
+  if (rc)
+    return rc;
+  // pixels of tiles this context does not own keep the caller's values
+  HIPCHK(hipMemcpyAsync(c->rowScratch.p, rgbOut, full * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_untile, dim3((c->geom.numLocalPixels + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->geom, tileMajorDev,
+                     c->rowScratch.p, c->geom.numLocalPixels);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(rgbOut, c->rowScratch.p, full * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int rthip_read_accumulator(rthip_ctx* c, float* rgbOut)
+{
+  if (!c || !rgbOut)
+    return RTHIP_E_ARG;
+  if (!c->haveFrame)
+    return RTHIP_E_STATE;
+  HIPCHK(hipSetDevice(c->device));
+  return readTiled(c, c->acc.p, rgbOut);
+}
+
+int rthip_read_image(rthip_ctx* c, float* rgbOut)
+{
+  if (!c || !rgbOut)
+    return RTHIP_E_ARG;
+  if (!c->haveFrame)
+    return RTHIP_E_STATE;
+  HIPCHK(hipSetDevice(c->device));
+  const uint32_t nf = c->geom.numLocalPixels * 3;
+  const float resolver = float(c->geom.numSamples) / float(c->lastSamp + 1); // CPURenderer.cpp:196
+  if (c->renderedAny)
+  {
+    hipLaunchKernelGGL(k_tonemap, dim3((nf + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->acc.p, c->img.p, nf, resolver);
+    HIPCHK(hipGetLastError());
+  }
+  return readTiled(c, c->img.p, rgbOut);
+}
+
+int rthip_read_aov(rthip_ctx* c, uint32_t samp, uint32_t depth, uint32_t* triIdOut, uint8_t* shadowOut)
+{
+  if (!c || !triIdOut || !shadowOut)
+    return RTHIP_E_ARG;
+  if (!c->haveFrame || !c->renderedAny || !c->aovDepths)
+    return RTHIP_E_STATE;
+  if (depth >= c->aovDepths || samp < c->lastBatchBegin || samp >= c->lastBatchBegin + c->lastBatchCount)
+    return RTHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  const uint32_t P = c->geom.numLocalPixels;
+  const size_t off = ((size_t)(samp - c->lastBatchBegin) * c->aovDepths + depth) * P;
+  std::vector<uint32_t> tri(P);
+  std::vector<uint8_t> sh(P);
+  HIPCHK(hipMemcpy(tri.data(), c->aovTri.p + off, P * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(sh.data(), c->aovShadow.p + off, P, hipMemcpyDeviceToHost));
+  const FrameGeom& g = c->geom;
+  const uint32_t ts = g.tileSize, per = ts * ts;
+  for (uint32_t i = 0; i < P; ++i)
+  {
+    const uint32_t lt = i / per, k = i - lt * per;
+    const uint32_t tile = c->hostTileIds[lt];
+    const uint32_t ty = tile / g.tilesX, tx = tile - ty * g.tilesX;
+    const uint32_t blk = k >> 6, l = k & 63u, bpr = ts >> 3;
+    const uint32_t by = blk / bpr, bx = blk - by * bpr;
+    const uint32_t w = tx * ts + bx * 8 + (l & 7u), h = ty * ts + by * 8 + (l >> 3);
+    if (w < g.width && h < g.height)
+    {
+      triIdOut[(size_t)h * g.width + w] = tri[i];
+      shadowOut[(size_t)h * g.width + w] = sh[i];
+    }
+  }
+  return 0;
+}
+
+int rthip_accumulator_device(rthip_ctx* c, float** devPtr, uint64_t* numFloats)
+{
+  if (!c || !devPtr || !numFloats)
+    return RTHIP_E_ARG;
+  if (!c->haveFrame)
+    return RTHIP_E_STATE;
+  *devPtr = c->acc.p;
+  *numFloats = (uint64_t)c->geom.numLocalPixels * 3;
+  return 0;
+}
+
+int rthip_untile(rthip_ctx* c, const float* tileMajorDev, const uint32_t* tileIds, uint32_t numTiles, float* rowMajorDev)
+{
+  if (!c || !tileMajorDev || !tileIds || !numTiles || !rowMajorDev)
+    return RTHIP_E_ARG;
+  if (!c->haveFrame)
+    return RTHIP_E_STATE;
+  HIPCHK(hipSetDevice(c->device));
+  const uint32_t ts = c->geom.tileSize;
+  const uint32_t tilesY = (c->geom.height + ts - 1) / ts;
+  for (uint32_t k = 0; k < numTiles; ++k)
+    if (tileIds[k] >= c->geom.tilesX * tilesY)
+      return RTHIP_E_ARG;
+  DevBuf<uint32_t> ids;
+  int rc = ids.ensure(numTiles);
+  if (rc)
+    return rc;
+  HIPCHK(hipMemcpy(ids.p, tileIds, sizeof(uint32_t) * numTiles, hipMemcpyHostToDevice));
+  FrameGeom g = c->geom;
+  g.tileIds = ids.p;
+  g.numLocalTiles = numTiles;
+  g.numLocalPixels = numTiles * ts * ts;
+  hipLaunchKernelGGL(k_untile, dim3((g.numLocalPixels + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, g, tileMajorDev, rowMajorDev,
+                     g.numLocalPixels);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  ids.release();
+  return 0;
+}
+
+int rthip_get_counters(rthip_ctx* c, rthip_counters* out)
+{
+  if (!c || !out)
+    return RTHIP_E_ARG;
+  *out = c->totals;
+  return 0;
+}
+
+int rthip_set_work_counting(rthip_ctx* c, int enabled)
+{
+  if (!c)
+    return RTHIP_E_ARG;
+  c->countWork = enabled != 0;
+  return 0;
+}
+
+int rthip_set_kernel_timing(rthip_ctx* c, int enabled)
+{
+  if (!c)
+    return RTHIP_E_ARG;
+  c->kernelTiming = enabled != 0;
+  return 0;
+}
+
+int rthip_get_kernel_times(rthip_ctx* c, float msOut[5], uint32_t launchesOut[5])
+{
+  if (!c || !msOut || !launchesOut)
+    return RTHIP_E_ARG;
+  for (int i = 0; i < 5; ++i)
+  {
+    msOut[i] = c->kernelMs[i];
+    launchesOut[i] = c->kernelLaunches[i];
+  }
+  return 0;
+}
+
+// ---- probes -------------------------------------------------------------------------------------
+int rthip_probe_rand01(rthip_ctx* c, const uint32_t* xyz, uint32_t n, float* out3)
+{
+  if (!c || !xyz || !out3 || !n)
+    return RTHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf<uint32_t> in;
+  DevBuf<float> out;
+  int rc;
+  if ((rc = in.ensure(3 * (size_t)n)) || (rc = out.ensure(3 * (size_t)n)))
+    return rc;
+  HIPCHK(hipMemcpy(in.p, xyz, 3 * (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_probe_rand01, dim3((n + 255) / 256), dim3(256), 0, c->stream, in.p, n, out.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(out3, out.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  in.release(), out.release();
+  return 0;
+}
+
+int rthip_probe_sincos(rthip_ctx* c, const float* x, uint32_t n, float* sinOut, float* cosOut)
+{
+  if (!c || !x || !sinOut || !cosOut || !n)
+    return RTHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf<float> in, s, co;
+  int rc;
+  if ((rc = in.ensure(n)) || (rc = s.ensure(n)) || (rc = co.ensure(n)))
+    return rc;
+  HIPCHK(hipMemcpy(in.p, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_probe_sincos, dim3((n + 255) / 256), dim3(256), 0, c->stream, in.p, n, s.p, co.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(sinOut, s.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(cosOut, co.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  in.release(), s.release(), co.release();
+  return 0;
+}
+
+int rthip_probe_primary_rays(rthip_ctx* c, const rthip_camera* cam, uint32_t width, uint32_t height, const uint32_t* whs, uint32_t n,
+                             float* origin3, float* dir3)
+{
+  if (!c || !cam || !whs || !origin3 || !dir3 || !n || !width || !height)
+    return RTHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf<uint32_t> in;
+  DevBuf<float> o, d;
+  DevBuf<CameraConsts> kc;
+  int rc;
+  if ((rc = in.ensure(3 * (size_t)n)) || (rc = o.ensure(3 * (size_t)n)) || (rc = d.ensure(3 * (size_t)n)) || (rc = kc.ensure(1)))
+    return rc;
+  HIPCHK(hipMemcpy(in.p, whs, 3 * (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_camera, dim3(1), dim3(64), 0, c->stream, *cam, kc.p);
+  hipLaunchKernelGGL(k_probe_rays, dim3((n + 255) / 256), dim3(256), 0, c->stream, kc.p, width, height, in.p, n, o.p, d.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(origin3, o.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(dir3, d.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  in.release(), o.release(), d.release(), kc.release();
+  return 0;
+}
+
+int rthip_probe_bounce(rthip_ctx* c, const float* normalLight3, const float* rnd3, uint32_t n, float* dir3)
+{
+  if (!c || !normalLight3 || !rnd3 || !dir3 || !n)
+    return RTHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf<float> a, b, o;
+  int rc;
+  if ((rc = a.ensure(3 * (size_t)n)) || (rc = b.ensure(3 * (size_t)n)) || (rc = o.ensure(3 * (size_t)n)))
+    return rc;
+  HIPCHK(hipMemcpy(a.p, normalLight3, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b.p, rnd3, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_probe_bounce, dim3((n + 255) / 256), dim3(256), 0, c->stream, a.p, b.p, n, o.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(dir3, o.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  a.release(), b.release(), o.release();
+  return 0;
+}
+
+int rthip_probe_trace(rthip_ctx* c, const float* origin3, const float* dir3, uint32_t n, float tmin, float tmax, uint32_t* triIdOut,
+                      float* tOut, uint8_t* anyOut)
+{
+  if (!c || !origin3 || !dir3 || !n || !triIdOut || !tOut || !anyOut)
+    return RTHIP_E_ARG;
+  if (!c->haveScene)
+    return RTHIP_E_STATE;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int rc;
+  if ((rc = ensurePathBuffers(c, n)) || (rc = c->anyOut.ensure(n)))
+    return rc;
+  c->haveFrame = false; // path buffers may have been reallocated
+  DevBuf<float> o, d, t;
+  DevBuf<uint32_t> id;
+  if ((rc = o.ensure(3 * (size_t)n)) || (rc = d.ensure(3 * (size_t)n)) || (rc = t.ensure(n)) || (rc = id.ensure(n)))
+    return rc;
+  HIPCHK(hipMemcpy(o.p, origin3, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d.p, dir3, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemsetAsync(c->fetch.p, 0, c->fetch.n * sizeof(uint32_t), c->stream));
+  HIPCHK(hipMemsetAsync(c->counters.p, 0, sizeof(DeviceCounters), c->stream));
+  hipLaunchKernelGGL(k_probe_pack, dim3((n + 255) / 256), dim3(256), 0, c->stream, o.p, d.p, n, c->rayO.p, c->rayD.p, c->live.p);
+  HIPCHK(hipGetLastError());
+  if ((rc = launchTrace<CLOSEST>(c, n, 0, 0, tmin, tmax)) || (rc = launchTrace<ANYPROBE>(c, n, 0, 1, tmin, tmax)))
+    return rc;
+  hipLaunchKernelGGL(k_probe_unpack, dim3((n + 255) / 256), dim3(256), 0, c->stream, devScene(c), c->hit.p, n, id.p, t.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(triIdOut, id.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(tOut, t.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(anyOut, c->anyOut.p, (size_t)n, hipMemcpyDeviceToHost));
+  o.release(), d.release(), t.release(), id.release();
+  return 0;
+}
+}

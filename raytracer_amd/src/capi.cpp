@@ -1,0 +1,271 @@
+// capi.cpp -- the C ABI of include/raytracer_c.h over the C++ Renderer interface.
+#include "raytracer_c.h"
+
+#include "hip/HIPRenderer.h"
+#include "util/ModelLoader.h"
+#include "util/Procedural.h"
+
+#include <cstring>
+#include <memory>
+#include <string>
+
+using namespace rt;
+
+struct rt_mesh
+{
+  PModel model;
+};
+
+struct rt_renderer
+{
+  std::unique_ptr<HIPRenderer> hip;
+  bool generated = false;
+};
+
+namespace
+{
+rt_mesh* wrap(PModel m)
+{
+  if (!m)
+    return nullptr;
+  auto* h = new rt_mesh();
+  h->model = std::move(m);
+  return h;
+}
+PModel cloneModel(const Model& src)
+{
+  auto m = std::make_unique<Model>();
+  m->boundingBox = src.boundingBox;
+  m->positions = src.positions;
+  m->texCoords = src.texCoords;
+  m->normals = src.normals;
+  m->indices = src.indices;
+  return m;
+}
+} // namespace
+
+extern "C" {
+
+rt_mesh* rt_mesh_cube(void) { return wrap(makeCube()); }
+rt_mesh* rt_mesh_soup(uint32_t numTriangles, uint64_t seed, float edgeRadius)
+{
+  return numTriangles ? wrap(makeTriangleSoup(numTriangles, seed, edgeRadius)) : nullptr;
+}
+rt_mesh* rt_mesh_heightfield(uint32_t quadsPerSide, uint64_t seed, float amplitude)
+{
+  return quadsPerSide ? wrap(makeHeightField(quadsPerSide, seed, amplitude)) : nullptr;
+}
+rt_mesh* rt_mesh_load_obj(const char* path)
+{
+  if (!path)
+    return nullptr;
+  std::vector<PModel> models = ModelLoader::loadModel(path);
+  if (models.empty())
+    return nullptr;
+  return wrap(std::move(models[0]));
+}
+rt_mesh* rt_mesh_from_arrays(const float* positions, uint32_t numPositions, const float* texCoords, const uint32_t* indices,
+                             uint32_t numTriangles)
+{
+  if (!positions || !indices || !numPositions || !numTriangles)
+    return nullptr;
+  for (uint32_t k = 0; k < 3 * numTriangles; ++k)
+    if (indices[k] >= numPositions)
+      return nullptr;
+  return wrap(Model::fromArrays(positions, numPositions, texCoords, indices, numTriangles));
+}
+uint32_t rt_mesh_num_positions(const rt_mesh* m) { return m ? (uint32_t)m->model->positions.size() : 0; }
+uint32_t rt_mesh_num_triangles(const rt_mesh* m) { return m ? (uint32_t)m->model->indices.size() : 0; }
+void rt_mesh_copy(const rt_mesh* m, float* positions3, uint32_t* indices3)
+{
+  if (!m)
+    return;
+  if (positions3)
+    std::memcpy(positions3, m->model->positions.data(), m->model->positions.size() * sizeof(vec3));
+  if (indices3)
+    std::memcpy(indices3, m->model->indices.data(), m->model->indices.size() * sizeof(uvec3));
+}
+void rt_mesh_destroy(rt_mesh* m) { delete m; }
+
+int rt_renderer_create(const char* backend, int device, rt_renderer** out)
+{
+  if (!backend || !out)
+    return RTHIP_E_ARG;
+  // "hip": the MI355X backend, fails without a device.  "hip-offline": same host code with no device, for
+  // inspecting the flattened scene; every render call fails with RTHIP_E_NODEVICE.  There is no CPU backend in
+  // this library (the CPU path lives in the test oracle).
+  const bool offline = std::strcmp(backend, "hip-offline") == 0;
+  if (!offline && std::strcmp(backend, "hip") != 0)
+    return RTHIP_E_ARG;
+  auto r = std::make_unique<rt_renderer>();
+  r->hip = std::make_unique<HIPRenderer>(offline ? -1 : device);
+  if (r->hip->lastError())
+    return r->hip->lastError();
+  *out = r.release();
+  return 0;
+}
+void rt_renderer_destroy(rt_renderer* r) { delete r; }
+
+int rt_add_directional_light(rt_renderer* r, const float d[3], const float c[3])
+{
+  if (!r || !d || !c)
+    return RTHIP_E_ARG;
+  DirectionalLight L;
+  L.direction = vec3{d[0], d[1], d[2]};
+  L.color = vec3{c[0], c[1], c[2]};
+  r->hip->addDirectionalLight(L);
+  return 0;
+}
+int rt_add_point_light(rt_renderer* r, const float p[3], const float c[3], float attenuation)
+{
+  if (!r || !p || !c)
+    return RTHIP_E_ARG;
+  PointLight L;
+  L.position = vec3{p[0], p[1], p[2]};
+  L.color = vec3{c[0], c[1], c[2]};
+  L.attenuation = attenuation;
+  r->hip->addPointLight(L);
+  return 0;
+}
+int rt_add_mesh(rt_renderer* r, const rt_mesh* m, const float transform[16])
+{
+  if (!r || !m || !transform)
+    return RTHIP_E_ARG;
+  if (r->generated)
+    return RTHIP_E_STATE;
+  mat4 t;
+  std::memcpy(&t, transform, sizeof(t));
+  r->hip->addModel(cloneModel(*m->model), t);
+  return 0;
+}
+int rt_generate(rt_renderer* r)
+{
+  if (!r)
+    return RTHIP_E_ARG;
+  if (r->generated)
+    return RTHIP_E_STATE; // the reference's generate() is one-shot too ("todo: clear everything", Scene.cpp:20)
+  r->hip->generate();
+  r->generated = true;
+  return r->hip->getScene()->lastError();
+}
+
+int rt_set_option(rt_renderer* r, const char* name, double value)
+{
+  if (!r || !name)
+    return RTHIP_E_ARG;
+  const std::string n(name);
+  HIPRenderOptions& o = r->hip->options;
+  FlattenOptions& fo = r->hip->getScene()->options;
+  const uint32_t u = value < 0 ? 0u : (uint32_t)value;
+  if (n == "maxDepth")
+    o.maxDepth = u;
+  else if (n == "aovDepths")
+    o.aovDepths = u;
+  else if (n == "tileSize")
+    o.tileSize = u;
+  else if (n == "passesPerCall")
+    o.passesPerCall = u;
+  else if (n == "referenceEdgeIndexing")
+    fo.referenceEdgeIndexing = value != 0;
+  else if (n == "maxLeafTriangles")
+    fo.maxLeafTriangles = u;
+  else if (n == "sahBins")
+    fo.sahBins = u;
+  else if (n == "buildThreads")
+    fo.threads = u;
+  else if (n == "originBoundScale")
+    fo.originBoundScale = (float)value;
+  else if (n == "countWork")
+    return r->hip->context() ? rthip_set_work_counting(r->hip->context(), value != 0) : RTHIP_E_NODEVICE;
+  else if (n == "kernelTiming")
+    return r->hip->context() ? rthip_set_kernel_timing(r->hip->context(), value != 0) : RTHIP_E_NODEVICE;
+  else
+    return RTHIP_E_ARG;
+  return 0;
+}
+int rt_set_tiles(rt_renderer* r, const uint32_t* tileIds, uint32_t numTiles)
+{
+  if (!r || (numTiles && !tileIds))
+    return RTHIP_E_ARG;
+  r->hip->options.tiles.assign(tileIds, tileIds + numTiles);
+  return 0;
+}
+
+int rt_start_render(rt_renderer* r, const rthip_camera* c, uint32_t width, uint32_t height, uint32_t numSamples)
+{
+  if (!r || !c)
+    return RTHIP_E_ARG;
+  if (!r->generated)
+    return RTHIP_E_STATE;
+  Camera cam;
+  cam.position = vec3{c->position[0], c->position[1], c->position[2]};
+  cam.target = vec3{c->target[0], c->target[1], c->target[2]};
+  cam.sensorSize = vec2{c->sensorSize[0], c->sensorSize[1]};
+  cam.S_O = c->S_O, cam.f = c->f, cam.A = c->A;
+  r->hip->startRender(cam, RenderParameter{width, height, numSamples});
+  return 0;
+}
+int rt_wait_render(rt_renderer* r)
+{
+  if (!r)
+    return RTHIP_E_ARG;
+  r->hip->waitRender();
+  return r->hip->lastError();
+}
+int rt_cancel_render(rt_renderer* r)
+{
+  if (!r)
+    return RTHIP_E_ARG;
+  r->hip->cancelRender();
+  return 0;
+}
+uint32_t rt_get_sample_times(rt_renderer* r, float* msOut, uint32_t cap)
+{
+  if (!r)
+    return 0;
+  const std::vector<float>& t = r->hip->getSampleTimes();
+  const uint32_t n = (uint32_t)t.size();
+  if (msOut)
+    std::memcpy(msOut, t.data(), sizeof(float) * std::min(n, cap));
+  return n;
+}
+int rt_read_accumulator(rt_renderer* r, float* rgb) { return r ? r->hip->readAccumulator(rgb) : RTHIP_E_ARG; }
+int rt_read_image(rt_renderer* r, float* rgb) { return r ? r->hip->readImage(rgb) : RTHIP_E_ARG; }
+int rt_read_aov(rt_renderer* r, uint32_t samp, uint32_t depth, uint32_t* triIdOut, uint8_t* shadowOut)
+{
+  if (!r)
+    return RTHIP_E_ARG;
+  return r->hip->context() ? rthip_read_aov(r->hip->context(), samp, depth, triIdOut, shadowOut) : RTHIP_E_NODEVICE;
+}
+int rt_get_counters(rt_renderer* r, rthip_counters* out)
+{
+  if (!r)
+    return RTHIP_E_ARG;
+  return r->hip->context() ? rthip_get_counters(r->hip->context(), out) : RTHIP_E_NODEVICE;
+}
+int rt_get_kernel_times(rt_renderer* r, float msOut[5], uint32_t launchesOut[5])
+{
+  if (!r)
+    return RTHIP_E_ARG;
+  return r->hip->context() ? rthip_get_kernel_times(r->hip->context(), msOut, launchesOut) : RTHIP_E_NODEVICE;
+}
+int rt_get_flat(rt_renderer* r, const rtflat_info** info, const rtflat_model_node** modelNodes, const rtflat_node** nodes,
+                const rtflat_tri** tris, double* buildSeconds)
+{
+  if (!r || !r->generated)
+    return RTHIP_E_STATE;
+  const FlatScene& f = r->hip->getScene()->flattened();
+  if (info)
+    *info = &f.info;
+  if (modelNodes)
+    *modelNodes = f.modelNodes.data();
+  if (nodes)
+    *nodes = f.nodes.data();
+  if (tris)
+    *tris = f.tris.data();
+  if (buildSeconds)
+    *buildSeconds = f.buildSeconds;
+  return 0;
+}
+rthip_ctx* rt_context(rt_renderer* r) { return r ? r->hip->context() : nullptr; }
+}

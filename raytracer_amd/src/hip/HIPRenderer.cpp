@@ -1,0 +1,77 @@
+#include "hip/HIPRenderer.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace rt
+{
+HIPRenderer::HIPRenderer(int device)
+{
+  // device < 0: offline mode -- the scene can be flattened and inspected, rendering fails with RTHIP_E_NODEVICE
+  if (device >= 0)
+  {
+    error = rthip_create(device, &ctx);
+    if (error)
+      std::fprintf(stderr, "HIPRenderer: %s\n", rthip_error_string(error));
+  }
+  scene = new HIPScene(ctx);
+}
+
+HIPRenderer::~HIPRenderer()
+{
+  cancelRender();
+  delete scene;
+  if (ctx)
+    rthip_destroy(ctx);
+}
+
+// Takes the place of CPURenderer::render (src/cpu/CPURenderer.cpp:138-207).  The device keeps the accumulator;
+// per-sample-pass times go to sampleTimes as in the reference (:204-205), here device milliseconds of a call
+// divided evenly over the passes it ran.
+void HIPRenderer::render(Camera cam, RenderParameter params)
+{
+  if (!ctx || scene->lastError())
+  {
+    error = ctx ? scene->lastError() : RTHIP_E_NODEVICE;
+    std::fprintf(stderr, "HIPRenderer: cannot render: %s\n", rthip_error_string(error));
+    return;
+  }
+  error = 0;
+  rthip_camera c;
+  std::memcpy(c.position, &cam.position, sizeof(c.position));
+  std::memcpy(c.target, &cam.target, sizeof(c.target));
+  c.sensorSize[0] = cam.sensorSize.x, c.sensorSize[1] = cam.sensorSize.y;
+  c.S_O = cam.S_O, c.f = cam.f, c.A = cam.A;
+  rthip_frame_desc frame{};
+  frame.width = params.width, frame.height = params.height, frame.numSamples = params.numSamples;
+  frame.maxDepth = options.maxDepth;
+  frame.aovDepths = options.aovDepths;
+  frame.tileSize = options.tileSize;
+  frame.numTiles = (uint32_t)options.tiles.size();
+  frame.tileIds = options.tiles.empty() ? nullptr : options.tiles.data();
+  error = rthip_begin(ctx, &c, &frame);
+  if (error)
+  {
+    std::fprintf(stderr, "HIPRenderer: rthip_begin: %s\n", rthip_error_string(error));
+    return;
+  }
+  uint32_t samp = 0;
+  while (samp < params.numSamples)
+  {
+    if (!running) // src/cpu/CPURenderer.cpp:146
+      return;
+    const uint32_t left = params.numSamples - samp;
+    const uint32_t n = options.passesPerCall ? std::min(options.passesPerCall, left) : left;
+    float ms = 0.0f;
+    error = rthip_render_passes(ctx, samp, n, &ms);
+    if (error)
+    {
+      std::fprintf(stderr, "HIPRenderer: rthip_render_passes: %s\n", rthip_error_string(error));
+      return;
+    }
+    for (uint32_t k = 0; k < n; ++k)
+      sampleTimes.push_back(ms / float(n));
+    samp += n;
+  }
+}
+} // namespace rt

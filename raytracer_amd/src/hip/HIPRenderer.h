@@ -1,0 +1,52 @@
+// HIPRenderer.h -- the MI355X backend behind the reference's Renderer interface, a sibling of CPURenderer
+// (src/cpu/CPURenderer.h:9-39): it forwards the scene mutators to its HIPScene and implements render() by
+// driving the HIP kernels through the C ABI of include/rthip.h.  No HIP header is included on the host side.
+#pragma once
+#include "hip/HIPScene.h"
+#include "scene/Renderer.h"
+
+namespace rt
+{
+// knobs the reference hard-codes or does not have
+struct HIPRenderOptions
+{
+  uint32_t maxDepth = 12;       // src/cpu/CPUScene.cpp:15
+  uint32_t aovDepths = 0;       // record hit-id / shadow AOVs for parity checks
+  uint32_t tileSize = 64;
+  std::vector<uint32_t> tiles;  // empty = whole image; otherwise the tiles this renderer owns (multi-GPU sharding)
+  uint32_t passesPerCall = 0;   // sample passes handed to the device per call (0 = all remaining); `running` is polled between calls
+};
+
+class HIPRenderer : public Renderer
+{
+public:
+  explicit HIPRenderer(int device = 0);
+  ~HIPRenderer() override;
+
+  void addPointLight(PointLight point) override { scene->addPointLight(point); }
+  void addDirectionalLight(DirectionalLight dir) override { scene->addDirectionalLight(dir); }
+  void addModel(PModel model, mat4 transform) override { scene->addModel(std::move(model), transform); }
+  void addModels(std::vector<PModel> models, mat4 transform) override { scene->addModels(std::move(models), transform); }
+  void generate() override { scene->generate(); }
+
+  // the reference's backends draw a window here; this one is headless
+  void beginFrame() override {}
+  void update() override {}
+
+  HIPRenderOptions options;
+  HIPScene* getScene() { return scene; }
+  rthip_ctx* context() { return ctx; }
+  int lastError() const { return error; }
+  // row-major width*height*3, valid after waitRender()
+  int readAccumulator(float* rgb) { return ctx ? rthip_read_accumulator(ctx, rgb) : RTHIP_E_NODEVICE; }
+  int readImage(float* rgb) { return ctx ? rthip_read_image(ctx, rgb) : RTHIP_E_NODEVICE; }
+
+protected:
+  void render(Camera cam, RenderParameter params) override;
+
+private:
+  rthip_ctx* ctx = nullptr;
+  HIPScene* scene = nullptr;
+  int error = 0;
+};
+} // namespace rt
