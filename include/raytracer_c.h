@@ -50,6 +50,11 @@ int rt_set_tiles(rt_renderer*, const uint32_t* tileIds, uint32_t numTiles);    /
 int rt_start_render(rt_renderer*, const rthip_camera* camera, uint32_t width, uint32_t height, uint32_t numSamples); /* ::startRender */
 int rt_wait_render(rt_renderer*);     /* joins the render thread; returns the render's error code */
 int rt_cancel_render(rt_renderer*);   /* running = false + join (Renderer.cpp:13-17) */
+/* synchronous stepping for hosts that run the `samp` loop themselves (src/cpu/CPURenderer.cpp:144): rt_begin_frame
+ * is render()'s prologue (:140-143), rt_render_passes runs passes [begin, begin+count) on the calling thread and
+ * reports the device time of the call */
+int rt_begin_frame(rt_renderer*, const rthip_camera* camera, uint32_t width, uint32_t height, uint32_t numSamples);
+int rt_render_passes(rt_renderer*, uint32_t begin, uint32_t count, float* msOut);
 uint32_t rt_get_sample_times(rt_renderer*, float* msOut, uint32_t cap);        /* ::getSampleTimes */
 int rt_read_accumulator(rt_renderer*, float* rgbOut);                          /* CPURenderer::accumulator */
 int rt_read_image(rt_renderer*, float* rgbOut);                                /* CPURenderer::image */

@@ -382,6 +382,13 @@ struct orc_scene
     }
     return true;
   }
+  // 1/d for the padded-box tests, clamped to +-1e18 so that an exactly axis-parallel ray (d == 0 -> 1/d == inf)
+  // keeps finite slab arithmetic (inf - inf would turn into a NaN that fmin/fmax silently drop)
+  static inline V3 flatInvDir(V3 d)
+  {
+    const V3 r = 1.0f / d;
+    return V3{fminf(fmaxf(r.x, -1e18f), 1e18f), fminf(fmaxf(r.y, -1e18f), 1e18f), fminf(fmaxf(r.z, -1e18f), 1e18f)};
+  }
   static inline void flatSlab(const float* lo, const float* hi, const V3& invD, const V3& oi, float& entry, float& exit)
   {
     const float ax = __builtin_fmaf(lo[0], invD.x, -oi.x), bx = __builtin_fmaf(hi[0], invD.x, -oi.x);
@@ -413,7 +420,7 @@ struct orc_scene
   {
     uint32_t roots[64], nRoots = 0;
     flatModelLeaves(fInfo.rootModelNode, ray, tmin, tmax, roots, nRoots, cnt);
-    const V3 invD = 1.0f / ray.direction;
+    const V3 invD = flatInvDir(ray.direction);
     const V3 oi = ray.origin * invD;
     float best = FLT_MAX, cull = FLT_MAX;
     uint32_t bestKey = 0, bestRec = RTFLAT_INVALID;
@@ -478,7 +485,7 @@ struct orc_scene
   {
     uint32_t roots[64], nRoots = 0;
     flatModelLeaves(fInfo.rootModelNode, ray, tmin, tmax, roots, nRoots, cnt);
-    const V3 invD = 1.0f / ray.direction;
+    const V3 invD = flatInvDir(ray.direction);
     const V3 oi = ray.origin * invD;
     uint32_t stack[128];
     for (uint32_t r = 0; r < nRoots; ++r)

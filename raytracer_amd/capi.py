@@ -123,6 +123,8 @@ def host_lib():
         L.rt_set_option.argtypes = [vp, C.c_char_p, C.c_double]
         L.rt_set_tiles.argtypes = [vp, up, C.c_uint32]
         L.rt_start_render.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32]
+        L.rt_begin_frame.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32]
+        L.rt_render_passes.argtypes = [vp, C.c_uint32, C.c_uint32, fp]
         L.rt_wait_render.argtypes = [vp]
         L.rt_cancel_render.argtypes = [vp]
         L.rt_get_sample_times.restype = C.c_uint32
@@ -271,6 +273,16 @@ class Renderer:
     def render(self, camera, width, height, num_samples):
         self.start_render(camera, width, height, num_samples)
         self.wait()
+
+    def begin_frame(self, camera, width, height, num_samples):
+        self._size = (int(height), int(width))
+        _check(host_lib().rt_begin_frame(self._h, C.byref(camera), int(width), int(height), int(num_samples)), "rt_begin_frame")
+
+    def render_passes(self, begin, count):
+        """Runs sample passes [begin, begin+count) synchronously; returns the device milliseconds of the call."""
+        ms = C.c_float(0)
+        _check(host_lib().rt_render_passes(self._h, int(begin), int(count), C.byref(ms)), "rt_render_passes")
+        return float(ms.value)
 
     def sample_times(self):
         n = host_lib().rt_get_sample_times(self._h, None, 0)

@@ -187,6 +187,14 @@ RTD int triangleTest(vec3 p0, vec3 e0, vec3 e1, vec3 o, vec3 d, float tmin, floa
   return 1;
 }
 
+// 1/d for the padded-box tests, clamped to +-1e18 so that an exactly axis-parallel ray (d == 0 -> 1/d == inf) keeps
+// finite slab arithmetic (inf - inf would turn into a NaN that fminf/fmaxf silently drop)
+RTD vec3 padInvDir(vec3 d)
+{
+  const vec3 r = rt::rcp3(d);
+  return vec3{fminf(fmaxf(r.x, -1e18f), 1e18f), fminf(fmaxf(r.y, -1e18f), 1e18f), fminf(fmaxf(r.z, -1e18f), 1e18f)};
+}
+
 // ---- conservative slab test for the padded triangle-BVH boxes (no counterpart in the reference)
 RTD void padSlab(vec3 lo, vec3 hi, vec3 invD, vec3 oi, float& entry, float& exit)
 {

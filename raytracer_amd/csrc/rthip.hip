@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
           const float4 rd = a.pb.rayD[slot];
           d = vec3{rd.x, rd.y, rd.z};
         }
-        invD = rt::rcp3(d); // AABB.h:49
+        invD = rtd::padInvDir(d);
         oi = o * invD;
         best = FLT_MAX;
         cull = FLT_MAX;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
           const rtflat_model_node* mn = modelNodes + mk;
           if (COUNT)
             nNodes++;
-          if (!rtd::refSlab(mn->lo, mn->hi, o, invD, a.tmin, a.tmax))
+          if (!rtd::refSlab(mn->lo, mn->hi, o, rt::rcp3(d) /* AABB.h:49 */, a.tmin, a.tmax))
           {
             mk += mn->subtreeSize; // subtree size: skip it
             continue;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
             {
               const rthip_dir_light& L = a.lights->dir[lightIdx];
               d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]};
-              invD = rt::rcp3(d);
+              invD = rtd::padInvDir(d);
               oi = o * invD;
               mk = 0;
               nRays++;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
           {
             const rthip_dir_light& L = a.lights->dir[lightIdx];
             d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]};
-            invD = rt::rcp3(d);
+            invD = rtd::padInvDir(d);
             oi = o * invD;
             mk = 0;
             sp = spLo = 0;

@@ -191,19 +191,38 @@ int rt_set_tiles(rt_renderer* r, const uint32_t* tileIds, uint32_t numTiles)
   return 0;
 }
 
+static Camera toCamera(const rthip_camera* c)
+{
+  Camera cam;
+  cam.position = vec3{c->position[0], c->position[1], c->position[2]};
+  cam.target = vec3{c->target[0], c->target[1], c->target[2]};
+  cam.sensorSize = vec2{c->sensorSize[0], c->sensorSize[1]};
+  cam.S_O = c->S_O, cam.f = c->f, cam.A = c->A;
+  return cam;
+}
 int rt_start_render(rt_renderer* r, const rthip_camera* c, uint32_t width, uint32_t height, uint32_t numSamples)
 {
   if (!r || !c)
     return RTHIP_E_ARG;
   if (!r->generated)
     return RTHIP_E_STATE;
-  Camera cam;
-  cam.position = vec3{c->position[0], c->position[1], c->position[2]};
-  cam.target = vec3{c->target[0], c->target[1], c->target[2]};
-  cam.sensorSize = vec2{c->sensorSize[0], c->sensorSize[1]};
-  cam.S_O = c->S_O, cam.f = c->f, cam.A = c->A;
-  r->hip->startRender(cam, RenderParameter{width, height, numSamples});
+  r->hip->startRender(toCamera(c), RenderParameter{width, height, numSamples});
   return 0;
+}
+int rt_begin_frame(rt_renderer* r, const rthip_camera* c, uint32_t width, uint32_t height, uint32_t numSamples)
+{
+  if (!r || !c)
+    return RTHIP_E_ARG;
+  if (!r->generated)
+    return RTHIP_E_STATE;
+  r->hip->cancelRender();
+  return r->hip->beginFrameRender(toCamera(c), RenderParameter{width, height, numSamples});
+}
+int rt_render_passes(rt_renderer* r, uint32_t begin, uint32_t count, float* msOut)
+{
+  if (!r)
+    return RTHIP_E_ARG;
+  return r->hip->renderPasses(begin, count, msOut);
 }
 int rt_wait_render(rt_renderer* r)
 {

@@ -25,18 +25,14 @@ HIPRenderer::~HIPRenderer()
     rthip_destroy(ctx);
 }
 
-// Takes the place of CPURenderer::render (src/cpu/CPURenderer.cpp:138-207).  The device keeps the accumulator;
-// per-sample-pass times go to sampleTimes as in the reference (:204-205), here device milliseconds of a call
-// divided evenly over the passes it ran.
-void HIPRenderer::render(Camera cam, RenderParameter params)
+int HIPRenderer::beginFrameRender(Camera cam, RenderParameter params)
 {
   if (!ctx || scene->lastError())
   {
     error = ctx ? scene->lastError() : RTHIP_E_NODEVICE;
     std::fprintf(stderr, "HIPRenderer: cannot render: %s\n", rthip_error_string(error));
-    return;
+    return error;
   }
-  error = 0;
   rthip_camera c;
   std::memcpy(c.position, &cam.position, sizeof(c.position));
   std::memcpy(c.target, &cam.target, sizeof(c.target));
@@ -51,10 +47,27 @@ void HIPRenderer::render(Camera cam, RenderParameter params)
   frame.tileIds = options.tiles.empty() ? nullptr : options.tiles.data();
   error = rthip_begin(ctx, &c, &frame);
   if (error)
-  {
     std::fprintf(stderr, "HIPRenderer: rthip_begin: %s\n", rthip_error_string(error));
+  return error;
+}
+
+int HIPRenderer::renderPasses(uint32_t begin, uint32_t count, float* ms)
+{
+  if (!ctx)
+    return error = RTHIP_E_NODEVICE;
+  error = rthip_render_passes(ctx, begin, count, ms);
+  if (error)
+    std::fprintf(stderr, "HIPRenderer: rthip_render_passes: %s\n", rthip_error_string(error));
+  return error;
+}
+
+// Takes the place of CPURenderer::render (src/cpu/CPURenderer.cpp:138-207).  The device keeps the accumulator;
+// per-sample-pass times go to sampleTimes as in the reference (:204-205), here device milliseconds of a call
+// divided evenly over the passes it ran.
+void HIPRenderer::render(Camera cam, RenderParameter params)
+{
+  if (beginFrameRender(cam, params))
     return;
-  }
   uint32_t samp = 0;
   while (samp < params.numSamples)
   {
@@ -63,12 +76,8 @@ void HIPRenderer::render(Camera cam, RenderParameter params)
     const uint32_t left = params.numSamples - samp;
     const uint32_t n = options.passesPerCall ? std::min(options.passesPerCall, left) : left;
     float ms = 0.0f;
-    error = rthip_render_passes(ctx, samp, n, &ms);
-    if (error)
-    {
-      std::fprintf(stderr, "HIPRenderer: rthip_render_passes: %s\n", rthip_error_string(error));
+    if (renderPasses(samp, n, &ms))
       return;
-    }
     for (uint32_t k = 0; k < n; ++k)
       sampleTimes.push_back(ms / float(n));
     samp += n;

@@ -41,6 +41,11 @@ public:
   int readAccumulator(float* rgb) { return ctx ? rthip_read_accumulator(ctx, rgb) : RTHIP_E_NODEVICE; }
   int readImage(float* rgb) { return ctx ? rthip_read_image(ctx, rgb) : RTHIP_E_NODEVICE; }
 
+  // synchronous stepping for hosts that run the sample loop themselves (bench, parity tests): beginFrameRender
+  // does what render() does before its loop, renderPasses runs passes [begin, begin+count) and returns device ms
+  int beginFrameRender(Camera cam, RenderParameter params);
+  int renderPasses(uint32_t begin, uint32_t count, float* ms);
+
 protected:
   void render(Camera cam, RenderParameter params) override;
 

@@ -59,14 +59,9 @@ RT_HD vec2 operator/(vec2 a, vec2 b) { return vec2{a.x / b.x, a.y / b.y}; }
 
 RT_HD float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 RT_HD vec3 cross(vec3 a, vec3 b) { return vec3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
-RT_HD float rt_sqrt(float x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __fsqrt_rn(x); // correctly rounded, as the host's sqrtf
-#else
-  return sqrtf(x);
-#endif
-}
+// sqrtf is correctly rounded on both sides: SSE sqrtss on the host; on gfx950 hipcc expands it to v_sqrt_f32 plus
+// the two-FMA fix-up under -fhip-fp32-correctly-rounded-divide-sqrt (__fsqrt_rn does NOT: it stays at 1 ulp).
+RT_HD float rt_sqrt(float x) { return __builtin_sqrtf(x); }
 RT_HD float length(vec3 v) { return rt_sqrt(dot(v, v)); }
 RT_HD vec3 normalize(vec3 v) { return v * (1.0f / rt_sqrt(dot(v, v))); }
 // the comparison forms of glm::min/max and std::min/max (they differ from fminf/fmaxf when a NaN is involved)
