@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark: Mrays/s (primary + secondary) of the MI355X backend.
+
+A "step" is one whole frame of the workload: frame prologue (clear) + every sample pass through
+generate / extend / shade / shadow / accumulate, and at N > 1 the RCCL gather of the accumulator to rank 0.
+At N = 1 the workload is BASELINE.json configs[1]: the reference's own scene (unit cube == res/models/cube.fbx,
+lights and camera of src/main.cpp:9-24) at 1920x1080, 16 spp, primary + shadow rays (depth cap 1).
+At N > 1 the image grows with N (N x the pixels, same camera) and its 64x64 tiles are dealt round-robin to the
+ranks, so per-GPU work is fixed: weak scaling.  value = rays cast by all ranks / wall time of the K timed steps.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cube|bunny|soup1m|hf10m]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md "Chip-level parameters")
+CPU_WORKERS = 14       # the box gives 16 host cores per GPU; the reference uses hardware_concurrency()-2 (ThreadPool.h:29)
+
+
+def weak_resolution(base_w, base_h, n):
+    """N x the pixels of the base frame: 1 -> 1920x1080, 2 -> 1920x2160, 4 -> 3840x2160, 8 -> 3840x4320."""
+    w, h, k = base_w, base_h, n
+    grow_h = True
+    while k > 1:
+        if grow_h:
+            h *= 2
+        else:
+            w *= 2
+        grow_h = not grow_h
+        k //= 2
+    return w, h
+
+
+def workloads():
+    from tests import scenes
+    return {
+        "cube": dict(spec=scenes.cube_scene, width=1920, height=1080, spp=16, max_depth=1, flat_cpu=False,
+                     name="cube (== res/models/cube.fbx, main.cpp scene) 1920x1080 16spp primary+shadow [BASELINE configs[1]]"),
+        "cube12": dict(spec=scenes.cube_scene, width=1920, height=1080, spp=16, max_depth=12, flat_cpu=False,
+                       name="cube 1920x1080 16spp full paths (depth cap 12)"),
+        "bunny": dict(spec=scenes.bunny_scene, width=1920, height=1080, spp=16, max_depth=1, flat_cpu=True,
+                      name="stanford-bunny.obj (69,451 tris) 1920x1080 16spp primary+shadow"),
+        "soup1m": dict(spec=lambda: scenes.soup_scene(1 << 20, 0x5EED0001, 0.02), width=1920, height=1080, spp=1, max_depth=4, flat_cpu=True,
+                       name="triangle soup 2^20 tris seed 0x5EED0001, 1920x1080 1spp primary+3 bounces [BASELINE configs[2]]"),
+        "hf10m": dict(spec=lambda: scenes.heightfield_scene(2236, 0x5EED0002), width=3840, height=2160, spp=4, max_depth=12, flat_cpu=True,
+                      name="height field 2236^2 quads = 9,999,392 tris seed 0x5EED0002, 3840x2160 4spp [BASELINE configs[3] scene]"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cube")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the bounded CPU-baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import raytracer_amd as ra
+    from raytracer_amd import dist as rdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = max(args.gpus, world) if world > 1 else 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+
+    wl = workloads()[args.workload]
+    spec = wl["spec"]()
+    width, height = weak_resolution(wl["width"], wl["height"], world)
+    spp, max_depth, ts = wl["spp"], wl["max_depth"], 64
+
+    r = spec.build_product(options=dict(maxDepth=max_depth), device=local_rank)
+    flat = r.flat()
+    assignment = rdist.assign_tiles(width, height, world, ts)
+    if world > 1:
+        r.set_tiles(assignment[rank])
+    cam = spec.product_camera()
+    hl = ra.capi.hip_lib()
+    ctx = r.context
+    n_local_floats = len(assignment[rank]) * ts * ts * 3 if world > 1 else None
+    local_buf = torch.empty((len(assignment[rank]) * ts * ts, 3), dtype=torch.float32, device=f"cuda:{local_rank}") if world > 1 else None
+    full_frame = torch.zeros((height, width, 3), dtype=torch.float32, device=f"cuda:{local_rank}") if (world > 1 and rank == 0) else None
+    gather_ms = []
+
+    def step():
+        r.begin_frame(cam, width, height, spp)
+        r.render_passes(0, spp)
+        if world > 1:
+            t0 = time.perf_counter()
+            rc = hl.rthip_copy_accumulator_to(ctx, local_buf.data_ptr(), n_local_floats)
+            assert rc == 0, ra.capi.error_string(rc)
+            bufs = rdist.gather_tiles(local_buf, assignment, rank, world, dist)
+            if rank == 0:
+                for src, tiles in zip(bufs, assignment):
+                    rc = hl.rthip_untile(ctx, src.data_ptr(), ra.capi._up(tiles), len(tiles), full_frame.data_ptr())
+                    assert rc == 0, ra.capi.error_string(rc)
+            torch.cuda.synchronize()
+            gather_ms.append((time.perf_counter() - t0) * 1e3)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    gather_ms.clear()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    cnt = r.counters()  # totals of the LAST frame (begin_frame resets them)
+    rays_local = cnt["extendPrimary"] + cnt["extendSecondary"] + cnt["shadow"]
+    t = torch.tensor([elapsed, float(rays_local), float(cnt["extendPrimary"]), float(cnt["extendSecondary"]), float(cnt["shadow"])],
+                     dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+    rays_frame = float(t[1])
+    ms_per_step = elapsed / args.steps * 1e3
+    value = rays_frame / (ms_per_step * 1e-3) / 1e6
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel: per-kernel HIP-event timing + algorithmic work counts, in separate untimed frames
+    r.set_option("kernelTiming", 1)
+    r.begin_frame(cam, width, height, spp)
+    r.render_passes(0, spp)
+    ktimes = r.kernel_times()
+    r.set_option("kernelTiming", 0)
+    r.set_option("countWork", 1)
+    r.begin_frame(cam, width, height, spp)
+    r.render_passes(0, spp)
+    wc = r.counters()
+    r.set_option("countWork", 0)
+    n_ext = wc["extendPrimary"] + wc["extendSecondary"]
+    n_paths = wc["extendPrimary"]
+    # ALGORITHMIC bytes: per ray 32 (ray record) + 16 (hit record; any-hit: 4) + 64 per node + 64 per triangle record
+    alg_bytes = {
+        "extend": 48.0 * n_ext + 64.0 * (wc["nodesVisitedExtend"] + wc["trisTestedExtend"]),
+        "shadow": 36.0 * wc["shadow"] + 64.0 * ((wc["nodesVisited"] - wc["nodesVisitedExtend"]) + (wc["trisTested"] - wc["trisTestedExtend"])),
+        "generate": 32.0 * n_paths,                      # one ray record written per camera sample
+        "shade": (32.0 + 16.0 + 32.0) * n_ext,           # ray + hit read, next ray written, per shaded ray
+        "accumulate": 24.0 * n_paths / spp + 12.0 * n_paths,  # accumulator read+write per pixel + one radiance per sample
+    }
+    dominant = max(ktimes, key=lambda k: ktimes[k][0])
+    k_ms, k_launches = ktimes[dominant]
+    achieved = alg_bytes[dominant] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            traffic = tj.get(args.workload, {}).get(dominant)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": {"extend": "k_trace<CLOSEST>", "shadow": "k_trace<SHADOW>", "generate": "k_generate",
+                                           "shade": "k_shade", "accumulate": "k_accumulate"}[dominant],
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes[dominant] / max(1, k_launches), 1),
+                "avg_launch_ms": round(k_ms / max(1, k_launches), 5), "launches_per_step": k_launches,
+                "nodes_per_extend_ray": round(wc["nodesVisitedExtend"] / max(1, n_ext), 3),
+                "tris_per_extend_ray": round(wc["trisTestedExtend"] / max(1, n_ext), 3),
+                "kernel_ms_per_step": {k: round(v[0], 4) for k, v in ktimes.items()}}
+
+    # ---- CPU baseline: the oracle (restated src/cpu ThreadPool path) on this box's host cores, bounded sample
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import binding as ob  # the checker / baseline, never the thing measured above
+        oracle = spec.build_oracle()
+        bw, bh = wl["width"], wl["height"]
+        if wl["flat_cpu"]:
+            oracle.set_flat(flat["model_nodes"], flat["nodes"], flat["tris"], flat["info_bytes"])
+        ocam = spec.oracle_camera()
+        # calibrate on a 1/16 window, then size the sample to the time budget
+        win = (bw // 2 - bw // 8, bh // 2 - bh // 8, bw // 2 + bw // 8, bh // 2 + bh // 8)
+        t1 = time.perf_counter()
+        res = oracle.render(ocam, bw, bh, spp, max_depth=max_depth, window=win, samples=(0, 1), workers=CPU_WORKERS, flat=wl["flat_cpu"])
+        cal = time.perf_counter() - t1
+        full_pass_est = cal * 16.0
+        if full_pass_est <= args.cpu_seconds:
+            passes = int(max(1, min(spp, args.cpu_seconds // max(full_pass_est, 1e-3))))
+            t1 = time.perf_counter()
+            res = oracle.render(ocam, bw, bh, spp, max_depth=max_depth, samples=(0, passes), workers=CPU_WORKERS, flat=wl["flat_cpu"])
+            cpu_s = time.perf_counter() - t1
+            sample = f"{passes} of {spp} sample passes of the full {bw}x{bh} frame"
+        else:
+            cpu_s = cal
+            sample = f"1 sample pass of the centre {win[2] - win[0]}x{win[3] - win[1]} window of the {bw}x{bh} frame"
+        oc = res["counters"]
+        cpu_rays = oc["extendPrimary"] + oc["extendSecondary"] + oc["shadow"]
+        cpu = {"value": round(cpu_rays / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": CPU_WORKERS, "kind": "port",
+               "sample": sample + (" (variant B: CPU walk of the same flattened BVH)" if wl["flat_cpu"] else
+                                   " (variant A: reference-faithful model tree + linear triangle scan)") +
+               f", ThreadPool restatement with {CPU_WORKERS} workers, g++ -O2 -ffp-contract=off",
+               "seconds": round(cpu_s, 3)}
+
+    out = {"metric": "Mrays/s (primary+secondary)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": wl["name"], "width": width, "height": height, "spp": spp, "max_depth": max_depth,
+                      "tris": int(flat["info"].numTris), "bvh_nodes": int(flat["info"].numNodes),
+                      "rays_per_step": int(rays_frame), "primary": int(t[2]), "secondary_extend": int(t[3]), "shadow": int(t[4]),
+                      "parallelism": f"tiles64-rr-x{world}" if world > 1 else "single",
+                      "gather_ms": round(float(np.mean(gather_ms)), 4) if gather_ms else None},
+           "roofline": roofline, "cpu_baseline": cpu}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,8 @@ typedef struct rthip_counters
   uint64_t trisTested;
   uint64_t nonFiniteAccepts;/* triangle tests that passed every rejection with a NaN: outside the parity domain */
   uint64_t hits[16];        /* closest hits per depth */
+  uint64_t nodesVisitedExtend; /* the closest-hit share of nodesVisited / trisTested (the rest is any-hit) */
+  uint64_t trisTestedExtend;
 } rthip_counters;
 
 /* creates a context on `device` (a HIP device ordinal); replaces nothing in the reference (it has no device) */
@@ -106,6 +108,9 @@ int rthip_read_aov(rthip_ctx* ctx, uint32_t samp, uint32_t depth, uint32_t* triI
 /* Device-side access for the multi-GPU gather: the context's accumulator in its own (tile-major) order.
  * *devPtr points at numPixels*3 floats; pixel k of local tile j is at ((j*tileSize*tileSize)+k)*3. */
 int rthip_accumulator_device(rthip_ctx* ctx, float** devPtr, uint64_t* numFloats);
+/* copies the context's tile-major accumulator (numFloats floats as reported above) into caller-owned DEVICE memory
+ * on the same GPU (e.g. a torch tensor's data_ptr feeding an RCCL gather) and waits for the copy */
+int rthip_copy_accumulator_to(rthip_ctx* ctx, float* dstDev, uint64_t numFloats);
 /* scatters a gathered tile-major buffer (device memory, tiles listed in tileIds) into a row-major
  * width*height*3 device image */
 int rthip_untile(rthip_ctx* ctx, const float* tileMajorDev, const uint32_t* tileIds, uint32_t numTiles, float* rowMajorDev);

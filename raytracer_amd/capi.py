@@ -30,7 +30,7 @@ class Camera(C.Structure):  # rthip_camera == the reference's Camera (src/util/C
 class Counters(C.Structure):  # rthip_counters
     _fields_ = [("extendPrimary", C.c_uint64), ("extendSecondary", C.c_uint64), ("shadow", C.c_uint64),
                 ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64), ("nonFiniteAccepts", C.c_uint64),
-                ("hits", C.c_uint64 * 16)]
+                ("hits", C.c_uint64 * 16), ("nodesVisitedExtend", C.c_uint64), ("trisTestedExtend", C.c_uint64)]
 
     def as_dict(self):
         d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "hits"}
@@ -85,6 +85,7 @@ def hip_lib():
         L.rthip_probe_trace.argtypes = [vp, fp, fp, C.c_uint32, C.c_float, C.c_float, up, fp, C.POINTER(C.c_uint8)]
         L.rthip_accumulator_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
         L.rthip_untile.argtypes = [vp, vp, up, C.c_uint32, vp]
+        L.rthip_copy_accumulator_to.argtypes = [vp, vp, C.c_uint64]
         L.rthip_render_passes.argtypes = [vp, C.c_uint32, C.c_uint32, fp]
         L.rthip_enqueue_passes.argtypes = [vp, C.c_uint32, C.c_uint32]
         L.rthip_synchronize.argtypes = [vp]

@@ -73,7 +73,7 @@ struct Lights
 // device-side tallies; one 64-bit word each, updated once per wave/block at kernel end
 struct DeviceCounters
 {
-  unsigned long long extendPrimary, extendSecondary, shadow, nodesVisited, trisTested, nonFinite;
+  unsigned long long extendPrimary, extendSecondary, shadow, nodesVisited, trisTested, nonFinite, nodesExtend, trisExtend;
   unsigned long long hits[16];
   unsigned long long alive[kMaxDepthSlots + 2]; // paths alive at each depth of the current batch
 };
@@ -482,9 +482,17 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
       atomicAdd(dst, nRays);
     }
     if (COUNT && nNodes)
+    {
       atomicAdd(&a.counters->nodesVisited, nNodes);
+      if (MODE == CLOSEST)
+        atomicAdd(&a.counters->nodesExtend, nNodes);
+    }
     if (COUNT && nTris)
+    {
       atomicAdd(&a.counters->trisTested, nTris);
+      if (MODE == CLOSEST)
+        atomicAdd(&a.counters->trisExtend, nTris);
+    }
   }
 }
 
@@ -882,6 +890,8 @@ void addCounters(rthip_counters& dst, const DeviceCounters& s)
   dst.nodesVisited += s.nodesVisited;
   dst.trisTested += s.trisTested;
   dst.nonFiniteAccepts += s.nonFinite;
+  dst.nodesVisitedExtend += s.nodesExtend;
+  dst.trisTestedExtend += s.trisExtend;
   for (int i = 0; i < 16; ++i)
     dst.hits[i] += s.hits[i];
 }
@@ -1320,6 +1330,20 @@ int rthip_accumulator_device(rthip_ctx* c, float** devPtr, uint64_t* numFloats)
     return RTHIP_E_STATE;
   *devPtr = c->acc.p;
   *numFloats = (uint64_t)c->geom.numLocalPixels * 3;
+  return 0;
+}
+
+int rthip_copy_accumulator_to(rthip_ctx* c, float* dstDev, uint64_t numFloats)
+{
+  if (!c || !dstDev)
+    return RTHIP_E_ARG;
+  if (!c->haveFrame)
+    return RTHIP_E_STATE;
+  if (numFloats != (uint64_t)c->geom.numLocalPixels * 3)
+    return RTHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(dstDev, c->acc.p, numFloats * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 

@@ -1,0 +1,76 @@
+"""Multi-GPU tile sharding: one process per GPU, full scene replica per rank, image tiles as the data-parallel unit,
+one gather of the fp32 accumulator at the end (RCCL over xGMI when the backend is `nccl`, gloo in the CPU tests).
+
+A path depends only on (w, h, samp), the camera and the scene (src/cpu/CPURenderer.cpp:156-198), so ranks never
+exchange anything while rendering; per-pixel accumulation over `samp` stays inside one rank, which keeps the
+assembled image bit-identical to a single-GPU render.
+"""
+import numpy as np
+
+
+def tile_grid(width, height, tile_size=64):
+    return (width + tile_size - 1) // tile_size, (height + tile_size - 1) // tile_size
+
+
+def assign_tiles(width, height, world_size, tile_size=64):
+    """Static round-robin ownership: rank r owns tiles r, r+world, ... of the row-major tile list.  Neighbouring tiles go
+    to different GPUs, so every rank sees a similar mix of cheap and expensive image regions."""
+    tx, ty = tile_grid(width, height, tile_size)
+    ids = np.arange(tx * ty, dtype=np.uint32)
+    return [ids[r::world_size].copy() for r in range(world_size)]
+
+
+def padded_tile_count(assignment):
+    return max(len(a) for a in assignment)
+
+
+def local_pixel_coords(tile_ids, width, height, tile_size=64):
+    """(w, h, valid) of every pixel of a rank's tile-major buffer, in the device's order: tiles in list order, 8x8 pixel
+    blocks row-major inside a tile, pixels row-major inside a block (raytracer_amd/csrc/rthip.hip pixelOf)."""
+    tx, _ = tile_grid(width, height, tile_size)
+    tile_ids = np.asarray(tile_ids, dtype=np.int64)
+    per = tile_size * tile_size
+    k = np.arange(per, dtype=np.int64)
+    blk, lane = k >> 6, k & 63
+    bpr = tile_size >> 3
+    px = (blk % bpr) * 8 + (lane & 7)
+    py = (blk // bpr) * 8 + (lane >> 3)
+    w = (tile_ids % tx)[:, None] * tile_size + px[None, :]
+    h = (tile_ids // tx)[:, None] * tile_size + py[None, :]
+    valid = (w < width) & (h < height)
+    return w.reshape(-1), h.reshape(-1), valid.reshape(-1)
+
+
+def to_tile_major(image, tile_ids, tile_size=64):
+    """Row-major (H, W, 3) -> the tile-major (numTiles*ts*ts, 3) buffer a rank owning `tile_ids` would hold."""
+    hgt, wid = image.shape[:2]
+    w, h, valid = local_pixel_coords(tile_ids, wid, hgt, tile_size)
+    out = np.zeros((w.size, 3), image.dtype)
+    out[valid] = image[h[valid], w[valid]]
+    return out
+
+
+def assemble(gathered, assignment, width, height, tile_size=64):
+    """Rank 0: scatter every rank's tile-major buffer into one row-major (H, W, 3) frame (numpy reference of
+    rthip_untile)."""
+    frame = np.zeros((height, width, 3), np.float32)
+    for buf, tiles in zip(gathered, assignment):
+        w, h, valid = local_pixel_coords(tiles, width, height, tile_size)
+        buf = np.asarray(buf).reshape(-1, 3)[: w.size]
+        frame[h[valid], w[valid]] = buf[valid]
+    return frame
+
+
+def gather_tiles(local, assignment, rank, world_size, dist, device=None):
+    """Gathers equal-sized (padded) tile-major tensors to rank 0.  `local` is a torch tensor (numLocalPixels, 3)."""
+    import torch
+    per_rank = padded_tile_count(assignment) * (local.shape[0] // max(1, len(assignment[rank])))
+    if local.shape[0] < per_rank:
+        pad = torch.zeros((per_rank - local.shape[0], 3), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], 0)
+    local = local.contiguous()
+    if world_size == 1:
+        return [local]
+    bufs = [torch.empty_like(local) for _ in range(world_size)] if rank == 0 else None
+    dist.gather(local, bufs, dst=0)
+    return bufs
