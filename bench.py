@@ -168,6 +168,7 @@ def main():
         "generate": 32.0 * n_paths,                      # one ray record written per camera sample
         "shade": (32.0 + 16.0 + 32.0) * n_ext,           # ray + hit read, next ray written, per shaded ray
         "accumulate": 24.0 * n_paths / spp + 12.0 * n_paths,  # accumulator read+write per pixel + one radiance per sample
+        "compact": 1.0 * n_paths,
     }
     dominant = max(ktimes, key=lambda k: ktimes[k][0])
     k_ms, k_launches = ktimes[dominant]
@@ -181,7 +182,7 @@ def main():
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": {"extend": "k_trace<CLOSEST>", "shadow": "k_trace<SHADOW>", "generate": "k_generate",
-                                           "shade": "k_shade", "accumulate": "k_accumulate"}[dominant],
+                                           "shade": "k_shade", "accumulate": "k_accumulate", "compact": "k_compact"}[dominant],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes[dominant] / max(1, k_launches), 1),
                 "avg_launch_ms": round(k_ms / max(1, k_launches), 5), "launches_per_step": k_launches,

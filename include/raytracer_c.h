@@ -42,7 +42,7 @@ int rt_add_mesh(rt_renderer*, const rt_mesh*, const float transform[16]);
 int rt_generate(rt_renderer*);                                                 /* Renderer::generate */
 
 /* options the reference hard-codes: name in {"maxDepth","aovDepths","tileSize","passesPerCall",
- * "referenceEdgeIndexing","maxLeafTriangles","sahBins","buildThreads","countWork","kernelTiming"};
+ * "referenceEdgeIndexing","maxLeafTriangles","sahBins","buildThreads","originBoundScale","countWork","kernelTiming","fusedPrimary"};
  * scene options must be set before rt_generate */
 int rt_set_option(rt_renderer*, const char* name, double value);
 int rt_set_tiles(rt_renderer*, const uint32_t* tileIds, uint32_t numTiles);    /* tiles this renderer owns; 0 = all */
@@ -60,7 +60,7 @@ int rt_read_accumulator(rt_renderer*, float* rgbOut);                          /
 int rt_read_image(rt_renderer*, float* rgbOut);                                /* CPURenderer::image */
 int rt_read_aov(rt_renderer*, uint32_t samp, uint32_t depth, uint32_t* triIdOut, uint8_t* shadowOut);
 int rt_get_counters(rt_renderer*, rthip_counters* out);
-int rt_get_kernel_times(rt_renderer*, float msOut[5], uint32_t launchesOut[5]);
+int rt_get_kernel_times(rt_renderer*, float msOut[6], uint32_t launchesOut[6]);
 
 /* the flattened scene (valid after rt_generate, owned by the renderer) */
 int rt_get_flat(rt_renderer*, const rtflat_info** info, const rtflat_model_node** modelNodes, const rtflat_node** nodes,

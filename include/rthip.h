@@ -118,10 +118,13 @@ int rthip_untile(rthip_ctx* ctx, const float* tileMajorDev, const uint32_t* tile
 int rthip_get_counters(rthip_ctx* ctx, rthip_counters* out); /* totals since rthip_begin */
 /* 1: count nodesVisited/trisTested in the traversal kernels (slower); 0: off (default) */
 int rthip_set_work_counting(rthip_ctx* ctx, int enabled);
+/* 1 (default): primary rays are generated inside the depth-0 extend kernel and never stored;
+ * 0: a stand-alone generate kernel writes them first (the A/B baseline) */
+int rthip_set_fused_primary(rthip_ctx* ctx, int enabled);
 /* per-kernel device milliseconds accumulated since rthip_begin (HIP events around every launch when enabled):
- * order generate, extend, shade, shadow, accumulate.  enable with rthip_set_kernel_timing(ctx,1). */
+ * order generate, extend, shade, shadow, accumulate, compact.  enable with rthip_set_kernel_timing(ctx,1). */
 int rthip_set_kernel_timing(rthip_ctx* ctx, int enabled);
-int rthip_get_kernel_times(rthip_ctx* ctx, float msOut[5], uint32_t launchesOut[5]);
+int rthip_get_kernel_times(rthip_ctx* ctx, float msOut[6], uint32_t launchesOut[6]);
 
 /* bit-exactness probes of the device arithmetic against the host (tests only): n inputs each */
 int rthip_probe_rand01(rthip_ctx* ctx, const uint32_t* xyz, uint32_t n, float* out3);

@@ -316,10 +316,10 @@ class Renderer:
         return c.as_dict()
 
     def kernel_times(self):
-        ms = np.zeros(5, np.float32)
-        n = np.zeros(5, np.uint32)
+        ms = np.zeros(6, np.float32)
+        n = np.zeros(6, np.uint32)
         _check(host_lib().rt_get_kernel_times(self._h, _fp(ms), _up(n)), "rt_get_kernel_times")
-        names = ("generate", "extend", "shade", "shadow", "accumulate")
+        names = ("generate", "extend", "shade", "shadow", "accumulate", "compact")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def flat(self):

@@ -42,6 +42,7 @@ struct CameraConsts
   vec3 focalPoint;
   vec2 sdim;
   float A;
+  float focalDot; // dot(focalPoint - lc, lensN): the numerator of CPURenderer.cpp:190, the same for every pixel
 };
 
 RTD CameraConsts cameraSetup(const rthip_camera& c)
@@ -61,6 +62,7 @@ RTD CameraConsts cameraSetup(const rthip_camera& c)
   k.lensY = rt::cross(k.lensN, k.lensX);                                                                  // :185
   k.focalPoint = k.origin + (c.S_O + S_I) * k.direction;                                                  // :189
   k.A = c.A;
+  k.focalDot = rt::dot(k.focalPoint - k.lc, k.lensN);                                                     // :190 (r.origin == lc)
   return k;
 }
 
@@ -69,8 +71,10 @@ RTD void primaryRay(const CameraConsts& k, uint32_t width, uint32_t height, uint
                     vec3& d)
 {
   const float r2x = 2.0f * rnd.x, r2y = 2.0f * rnd.y;                                            // :171
-  const float tentx = r2x < 1 ? rt::rt_sqrt(r2x) - 1 : 1 - rt::rt_sqrt(2 - r2x);                 // :172-173
-  const float tenty = r2y < 1 ? rt::rt_sqrt(r2y) - 1 : 1 - rt::rt_sqrt(2 - r2y);
+  // :172-173  rnd2 < 1 ? sqrt(rnd2) - 1 : 1 - sqrt(2 - rnd2), written with one square root per axis
+  const float qx = rt::rt_sqrt(r2x < 1 ? r2x : 2 - r2x), qy = rt::rt_sqrt(r2y < 1 ? r2y : 2 - r2y);
+  const float tentx = r2x < 1 ? qx - 1 : 1 - qx;
+  const float tenty = r2y < 1 ? qy - 1 : 1 - qy;
   const int isamp = (int)samp;
   const float strx = (float)((isamp / 2) % 2), stry = (float)(isamp % 2);
   const float sx = (((float)w + 0.5f * ((0.5f + strx) + tentx)) / (float)width - 0.5f) * k.sdim.x; // :174-177
@@ -78,7 +82,7 @@ RTD void primaryRay(const CameraConsts& k, uint32_t width, uint32_t height, uint
   const vec3 spos = k.origin + k.cx * sx + k.cy * sy;                                             // :178
   const vec3 rdir = rt::normalize(k.lc - spos);                                                   // :179 (origin lc)
   const vec3 lensSample = k.lc + (rnd.x * k.A) * k.lensX + (rnd.y * k.A) * k.lensY;               // :187
-  const float t = rt::dot(k.focalPoint - k.lc, k.lensN) / rt::dot(rdir, k.lensN);                 // :190
+  const float t = k.focalDot / rt::dot(rdir, k.lensN);                                            // :190
   const vec3 focus = k.lc + t * rdir;                                                             // :191
   o = lensSample;
   d = rt::normalize(focus - lensSample);                                                          // :192

@@ -39,19 +39,22 @@ namespace
 {
 constexpr uint32_t kBlock = 256;       // 4 waves
 constexpr uint32_t kWavesPerBlock = kBlock / 64;
-constexpr uint32_t kChunk = 512;       // slots per work fetch
+constexpr uint32_t kChunk = 512;       // work items a wave scans and compacts at a time
 constexpr uint32_t kStackLds = 16;     // stack entries per lane kept in LDS
-constexpr uint32_t kSpillCap = 48;     // per-lane spill entries in global memory (stack depth <= kStackLds + kSpillCap)
+constexpr uint32_t kMaxStack = 96;     // deepest triangle BVH accepted (LDS part + spill)
 constexpr uint32_t kRefillThreshold = 16; // refill once this many lanes are idle (or no lane is active)
-constexpr uint8_t kDead = 0xff;
+constexpr uint32_t kMaxRun = 1024;     // most work items one wave is handed
+constexpr uint8_t kDead = 0xff;        // path finished, radiance in s0
+constexpr uint8_t kDeadZero = 0xfe;    // path finished with exactly zero radiance (primary miss) or pixel outside the image
 constexpr uint32_t kMaxLights = 8;
 constexpr uint32_t kMaxDepthSlots = 64;
 
 enum TraceMode
 {
-  CLOSEST = 0,
-  SHADOW = 1,
-  ANYPROBE = 2
+  CLOSEST = 0,  // closest hit of the stored ray (depth >= 1, or depth 0 when primary rays are stored)
+  SHADOW = 1,   // any-hit toward every directional light from the stored origin
+  ANYPROBE = 2, // any-hit of the stored ray (probe entry point)
+  PRIMARY = 3   // ray generation fused in: the primary ray is computed in registers, never stored
 };
 
 struct DeviceScene
@@ -76,14 +79,17 @@ struct DeviceCounters
   unsigned long long extendPrimary, extendSecondary, shadow, nodesVisited, trisTested, nonFinite, nodesExtend, trisExtend;
   unsigned long long hits[16];
   unsigned long long alive[kMaxDepthSlots + 2]; // paths alive at each depth of the current batch
+  uint32_t listCount[kMaxDepthSlots + 2];       // sparse mode: entries of the slot list of each depth
 };
 
 struct FrameGeom
 {
   uint32_t width, height, numSamples;
   uint32_t tileSize, tilesX, numLocalTiles;
-  uint32_t numLocalPixels; // P
-  const uint32_t* tileIds; // device, numLocalTiles entries
+  uint32_t numLocalPixels;  // P = numLocalTiles * tileSize^2
+  uint32_t tileShift;       // log2(tileSize); tiles are powers of two so that pixel decoding is shifts and masks
+  uint32_t sampleMagic;     // ceil(2^32 / numLocalTiles) (0 when numLocalTiles == 1): slot -> sample index without a division
+  const uint32_t* tileXY;   // device, numLocalTiles entries: x0 | y0 << 16, the tile's first pixel
 };
 
 struct PathBuffers
@@ -93,7 +99,7 @@ struct PathBuffers
   uint2* hit;    // x = float bits of t, y = triangle record index or RTFLAT_INVALID
   float4* s0;    // radiance.xyz, material.x
   float4* s1;    // material.y, material.z, previous normal.x, previous normal.y
-  uint8_t* live; // depth at which the path is waiting, kDead when finished / outside the image
+  uint8_t* live; // depth at which the path is waiting, kDead / kDeadZero when finished
   uint8_t* mask; // occlusion bits of the previous hit's shadow rays
 };
 
@@ -103,17 +109,33 @@ __device__ __forceinline__ uint32_t rankIn(uint64_t m)
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// MI355X deals consecutive workgroups round-robin to its 8 XCDs (each with a private L2).  This bijective remap
+// hands every XCD one contiguous range of work instead, so neighbouring image regions -- which walk the same BVH
+// subtrees -- share an L2.  Performance only: nothing depends on where a block runs.
+__device__ __forceinline__ uint32_t xcdRemap(uint32_t b, uint32_t nb)
+{
+  const uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u, i = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// slot -> (sample index within the batch, local pixel index)
+__device__ __forceinline__ void sampleOf(const FrameGeom& g, uint32_t slot, uint32_t& s, uint32_t& i)
+{
+  const uint32_t t = slot >> (2u * g.tileShift); // global tile slot = s * numLocalTiles + local tile
+  s = g.sampleMagic ? __umulhi(t, g.sampleMagic) : t;
+  i = slot - s * g.numLocalPixels;
+}
+
 // local pixel index -> image pixel; 8x8 pixel blocks are contiguous so a wave covers a compact footprint
 __device__ __forceinline__ bool pixelOf(const FrameGeom& g, uint32_t i, uint32_t& w, uint32_t& h)
 {
-  const uint32_t ts = g.tileSize, per = ts * ts;
-  const uint32_t lt = i / per, k = i - lt * per;
-  const uint32_t tile = g.tileIds ? g.tileIds[lt] : lt;
-  const uint32_t ty = tile / g.tilesX, tx = tile - ty * g.tilesX;
-  const uint32_t blk = k >> 6, l = k & 63u, bpr = ts >> 3;
-  const uint32_t by = blk / bpr, bx = blk - by * bpr;
-  w = tx * ts + bx * 8 + (l & 7u);
-  h = ty * ts + by * 8 + (l >> 3);
+  const uint32_t sh = g.tileShift;
+  const uint32_t lt = i >> (2u * sh), k = i & ((1u << (2u * sh)) - 1u);
+  const uint32_t xy = g.tileXY[lt];
+  const uint32_t blk = k >> 6, l = k & 63u;
+  const uint32_t by = blk >> (sh - 3u), bx = blk & ((1u << (sh - 3u)) - 1u);
+  w = (xy & 0xffffu) + bx * 8u + (l & 7u);
+  h = (xy >> 16) + by * 8u + (l >> 3);
   return w < g.width && h < g.height;
 }
 
@@ -124,17 +146,18 @@ __global__ void k_camera(rthip_camera cam, CameraConsts* out)
     *out = rtd::cameraSetup(cam);
 }
 
+// stand-alone ray generation (used when primary-ray fusion is switched off, and as the A/B baseline for it)
 __global__ __launch_bounds__(kBlock) void k_generate(FrameGeom g, const CameraConsts* camp, PathBuffers pb, uint32_t sampBegin,
                                                      uint32_t numPaths)
 {
   const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= numPaths)
     return;
-  const uint32_t s = p / g.numLocalPixels, i = p - s * g.numLocalPixels;
-  uint32_t w, h;
+  uint32_t s, i, w, h;
+  sampleOf(g, p, s, i);
   if (!pixelOf(g, i, w, h))
   {
-    pb.live[p] = kDead;
+    pb.live[p] = kDeadZero;
     return;
   }
   const CameraConsts k = *camp;
@@ -152,27 +175,31 @@ struct TraceArgs
 {
   DeviceScene scene;
   PathBuffers pb;
-  Lights* lights;          // SHADOW only
-  uint32_t numSlots;       // S*P
-  uint32_t depth;          // live[] value this launch serves
-  uint32_t* fetchCounter;  // zeroed before the launch
-  uint32_t* spill;         // [kSpillCap][gridLanes]
+  const Lights* lights;      // SHADOW only
+  FrameGeom geom;            // PRIMARY only
+  const CameraConsts* cam;   // PRIMARY only
+  uint32_t sampBegin;        // PRIMARY only
+  uint32_t numSlots;         // dense: S*P work items, item == slot
+  const uint32_t* list;      // sparse: work item -> slot; nullptr in dense mode
+  const uint32_t* listCount; // sparse: number of work items (device memory)
+  uint32_t runLen;           // work items per wave (multiple of 64, <= kMaxRun)
+  uint32_t depth;            // live[] value this launch serves (dense mode filter)
+  uint32_t* spill;           // [spillCap][gridLanes]
   DeviceCounters* counters;
   float tmin, tmax;
-  // ANYPROBE / probe outputs
-  uint8_t* anyOut;
+  uint8_t* anyOut;           // ANYPROBE
 };
 
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
 {
   __shared__ uint32_t sStack[kWavesPerBlock][kStackLds][64];
-  __shared__ uint16_t sList[kWavesPerBlock][kChunk];
+  __shared__ uint32_t sList[kWavesPerBlock][kChunk];
 
   const uint32_t lane = laneId();
   const uint32_t wv = threadIdx.x >> 6;
   uint32_t(*stack)[64] = sStack[wv];
-  uint16_t* list = sList[wv];
+  uint32_t* list = sList[wv];
   const uint32_t gridLanes = gridDim.x * kBlock;
   uint32_t* spill = a.spill + (blockIdx.x * kBlock + threadIdx.x);
 
@@ -180,11 +207,16 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
   const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(a.scene.nodes);
   const float4* __restrict__ tris4 = reinterpret_cast<const float4*>(a.scene.tris);
   const uint32_t numModelNodes = a.scene.numModelNodes;
-  const uint32_t numChunks = (a.numSlots + kChunk - 1) / kChunk;
+
+  // this wave's run of work items
+  const bool sparse = a.list != nullptr;
+  const uint32_t total = sparse ? *a.listCount : a.numSlots;
+  const uint32_t wid = xcdRemap(blockIdx.x, gridDim.x) * kWavesPerBlock + wv;
+  uint32_t runNext = min(total, wid * a.runLen);
+  const uint32_t runEnd = min(total, runNext + a.runLen);
 
   // wave-uniform work-list state
-  uint32_t chunkBase = 0, listCount = 0, listNext = 0;
-  bool moreChunks = true;
+  uint32_t listCount = 0, listNext = 0;
 
   // per-lane ray state
   bool active = false;
@@ -197,41 +229,47 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
   uint32_t sp = 0, spLo = 0;     // stack entries [spLo, sp) are in LDS, [0, spLo) spilled
   uint32_t lightIdx = 0;         // SHADOW: which directional light this lane is testing
   uint32_t occluded = 0;         // SHADOW: result bits
-  unsigned long long nRays = 0, nNodes = 0, nTris = 0;
+  uint32_t nRays = 0, nNodes = 0, nTris = 0;
 
   for (;;)
   {
-    // ---------------- work list: fetch + compact the next chunk when the list has run dry
+    // ---------------- work list: scan + compact the next chunk of the run when the list has run dry
     const uint64_t idleMask = __ballot(!active);
     const uint32_t numIdle = __popcll(idleMask);
-    if (listNext >= listCount && moreChunks && (numIdle >= kRefillThreshold))
+    if (listNext >= listCount && runNext < runEnd && numIdle >= kRefillThreshold)
     {
-      uint32_t c = 0;
-      if (lane == 0)
-        c = atomicAdd(a.fetchCounter, 1u);
-      c = __builtin_amdgcn_readfirstlane(c);
-      if (c >= numChunks)
-        moreChunks = false;
-      else
+      const uint32_t chunkEnd = min(runEnd, runNext + kChunk);
+      uint32_t n = 0;
+      for (uint32_t base = runNext; base < chunkEnd; base += 64)
       {
-        chunkBase = c * kChunk;
-        uint32_t n = 0;
-#pragma unroll 4
-        for (uint32_t j = 0; j < kChunk / 64; ++j)
+        const uint32_t item = base + lane;
+        bool isLive = item < chunkEnd;
+        uint32_t s = item;
+        if (sparse)
         {
-          const uint32_t s = chunkBase + j * 64 + lane;
-          const bool isLive = (s < a.numSlots) && (a.pb.live[s] == (uint8_t)a.depth);
-          const uint64_t m = __ballot(isLive);
           if (isLive)
-            list[n + rankIn(m)] = (uint16_t)(j * 64 + lane);
-          n += __popcll(m);
+            s = a.list[item];
         }
-        listCount = n;
-        listNext = 0;
-        // the list is written and read by this wave only; LDS ops of one wave complete in order
+        else if (MODE == PRIMARY)
+        {
+          // every slot of a primary launch carries a camera sample unless its pixel lies outside the image
+          uint32_t sidx, i, w, h;
+          sampleOf(a.geom, item, sidx, i);
+          isLive = isLive && pixelOf(a.geom, i, w, h);
+        }
+        else
+          isLive = isLive && (a.pb.live[item] == (uint8_t)a.depth);
+        const uint64_t m = __ballot(isLive);
+        if (isLive)
+          list[n + rankIn(m)] = s;
+        n += __popcll(m);
       }
+      runNext = chunkEnd;
+      listCount = n;
+      listNext = 0;
+      // the list is written and read by this wave only; LDS operations of one wave complete in order
     }
-    // ---------------- hand list entries to idle lanes
+    // ---------------- hand list entries to idle lanes (ballot + mbcnt compaction)
     const uint32_t avail = listCount - listNext;
     if (avail > 0 && (numIdle >= kRefillThreshold || numIdle == 64))
     {
@@ -239,20 +277,31 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
       const bool take = !active && r < avail;
       if (take)
       {
-        slot = chunkBase + list[listNext + r];
-        const float4 ro = a.pb.rayO[slot];
-        o = vec3{ro.x, ro.y, ro.z};
-        if (MODE == SHADOW)
+        slot = list[listNext + r];
+        if (MODE == PRIMARY)
         {
-          lightIdx = 0;
-          occluded = 0;
-          const rthip_dir_light& L = a.lights->dir[0];
-          d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]}; // Ray(position, -d.direction), CPUScene.cpp:34
+          uint32_t sidx, i, w, h;
+          sampleOf(a.geom, slot, sidx, i);
+          pixelOf(a.geom, i, w, h);
+          const uint32_t samp = a.sampBegin + sidx;
+          rtd::primaryRay(*a.cam, a.geom.width, a.geom.height, w, h, samp, rtd::rand01(w, h, samp), o, d);
         }
         else
         {
-          const float4 rd = a.pb.rayD[slot];
-          d = vec3{rd.x, rd.y, rd.z};
+          const float4 ro = a.pb.rayO[slot];
+          o = vec3{ro.x, ro.y, ro.z};
+          if (MODE == SHADOW)
+          {
+            lightIdx = 0;
+            occluded = 0;
+            const rthip_dir_light& L = a.lights->dir[0];
+            d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]}; // Ray(position, -d.direction), CPUScene.cpp:34
+          }
+          else
+          {
+            const float4 rd = a.pb.rayD[slot];
+            d = vec3{rd.x, rd.y, rd.z};
+          }
         }
         invD = rtd::padInvDir(d);
         oi = o * invD;
@@ -269,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
     }
     if (__ballot(active) == 0)
     {
-      if (!moreChunks && listNext >= listCount)
+      if (runNext >= runEnd && listNext >= listCount)
         break;
       continue;
     }
@@ -289,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
             nNodes++;
           if (!rtd::refSlab(mn->lo, mn->hi, o, rt::rcp3(d) /* AABB.h:49 */, a.tmin, a.tmax))
           {
-            mk += mn->subtreeSize; // subtree size: skip it
+            mk += mn->subtreeSize; // skip the subtree
             continue;
           }
           mk++;
@@ -305,7 +354,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
           bool done = true;
           if (MODE == SHADOW)
           {
-            // not occluded for this light; next light restarts the walk
+            // not occluded for this light; the next light restarts the walk
             lightIdx++;
             if (lightIdx < a.lights->numDir)
             {
@@ -320,7 +369,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
             else
               a.pb.mask[slot] = (uint8_t)occluded;
           }
-          else if (MODE == CLOSEST)
+          else if (MODE == CLOSEST || MODE == PRIMARY)
             a.pb.hit[slot] = make_uint2(__float_as_uint(best), bestRec);
           else
             a.anyOut[slot] = 0;
@@ -340,8 +389,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
       rtd::padSlab(vec3{q0.x, q0.y, q0.z}, vec3{q0.w, q1.x, q1.y}, invD, oi, en0, ex0);
       rtd::padSlab(vec3{q1.z, q1.w, q2.x}, vec3{q2.y, q2.z, q2.w}, invD, oi, en1, ex1);
       const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-      const bool h0 = (en0 <= ex0) && (MODE != CLOSEST || en0 <= cull);
-      const bool h1 = (en1 <= ex1) && (MODE != CLOSEST || en1 <= cull);
+      constexpr bool kClosest = (MODE == CLOSEST || MODE == PRIMARY);
+      const bool h0 = (en0 <= ex0) && (!kClosest || en0 <= cull);
+      const bool h1 = (en1 <= ex1) && (!kClosest || en1 <= cull);
       if (h0 && h1)
       {
         const bool swap = en1 < en0;
@@ -395,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
           atomicAdd(&a.counters->nonFinite, 1ull);
         if (acc != 1)
           continue;
-        if (MODE == CLOSEST)
+        if (MODE == CLOSEST || MODE == PRIMARY)
         {
           bool better = t < best;
           if (!better && t == best)
@@ -417,7 +467,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
           break;
         }
       }
-      if (MODE != CLOSEST && anyAccepted)
+      if (MODE != CLOSEST && MODE != PRIMARY && anyAccepted)
       {
         // first accepted triangle ends an any-hit ray (testModel returns true, CPUScene.cpp:182)
         bool done = true;
@@ -478,20 +528,21 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
   {
     if (nRays)
     {
-      unsigned long long* dst = (MODE == SHADOW) ? &a.counters->shadow : (a.depth == 0 ? &a.counters->extendPrimary : &a.counters->extendSecondary);
-      atomicAdd(dst, nRays);
+      unsigned long long* dst =
+          (MODE == SHADOW) ? &a.counters->shadow : ((MODE == PRIMARY || a.depth == 0) ? &a.counters->extendPrimary : &a.counters->extendSecondary);
+      atomicAdd(dst, (unsigned long long)nRays);
     }
     if (COUNT && nNodes)
     {
-      atomicAdd(&a.counters->nodesVisited, nNodes);
-      if (MODE == CLOSEST)
-        atomicAdd(&a.counters->nodesExtend, nNodes);
+      atomicAdd(&a.counters->nodesVisited, (unsigned long long)nNodes);
+      if (MODE == CLOSEST || MODE == PRIMARY)
+        atomicAdd(&a.counters->nodesExtend, (unsigned long long)nNodes);
     }
     if (COUNT && nTris)
     {
-      atomicAdd(&a.counters->trisTested, nTris);
-      if (MODE == CLOSEST)
-        atomicAdd(&a.counters->trisExtend, nTris);
+      atomicAdd(&a.counters->trisTested, (unsigned long long)nTris);
+      if (MODE == CLOSEST || MODE == PRIMARY)
+        atomicAdd(&a.counters->trisExtend, (unsigned long long)nTris);
     }
   }
 }
@@ -503,14 +554,19 @@ struct ShadeArgs
   DeviceScene scene;
   PathBuffers pb;
   const Lights* lights;
+  const CameraConsts* cam;
   DeviceCounters* counters;
   uint32_t numSlots, depth, maxDepth, sampBegin;
-  uint32_t finalFold; // 1: only fold the pending lights and finish every path (depth == maxDepth)
+  uint32_t finalFold;      // 1: only fold the pending lights and finish every path (depth == maxDepth)
+  uint32_t primaryInRegs;  // 1: depth-0 rays were never stored; recompute them from (pixel, sample)
   uint32_t aovDepths;
-  uint32_t* aovTri;   // [S][aovDepths][P]
-  uint8_t* aovShadow; // [S][aovDepths][P]
+  uint32_t* aovTri;        // [S][aovDepths][P]
+  uint8_t* aovShadow;      // [S][aovDepths][P]
+  const uint32_t* list;    // sparse mode: slots alive at `depth` (nullptr = dense)
+  uint32_t* listNext;      // sparse mode: survivors are appended here (count in counters->listCount[depth+1])
 };
 
+template <bool SPARSE>
 __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
 {
   __shared__ uint32_t sAlive[kWavesPerBlock], sHits[kWavesPerBlock];
@@ -518,90 +574,161 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
   const uint8_t depthTag = (uint8_t)a.depth;
   const vec3 albedo{0.0f, 1.0f, 0.0f};    // CPUScene.cpp:245
   const vec3 emissive{0.0f, 0.0f, 0.0f};  // CPUScene.cpp:246
-  for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < a.numSlots; p += gridDim.x * kBlock)
+  const uint32_t total = SPARSE ? a.counters->listCount[a.depth] : a.numSlots;
+  // every wave runs the same number of iterations so that the sparse append can use wave-wide ballots
+  const uint32_t stride = gridDim.x * kBlock;
+  const uint32_t iters = (total + stride - 1) / stride;
+  for (uint32_t it = 0; it < iters; ++it)
   {
-    if (a.pb.live[p] != depthTag)
-      continue;
-    const uint32_t s = p / a.g.numLocalPixels, i = p - s * a.g.numLocalPixels;
-    const float4 ro = a.pb.rayO[p], rd = a.pb.rayD[p];
-    const vec3 o{ro.x, ro.y, ro.z}, d{rd.x, rd.y, rd.z};
-    vec3 radiance{0.0f, 0.0f, 0.0f}, material{1.0f, 1.0f, 1.0f}; // Ray.h:7-8
-    if (a.depth > 0)
+    const uint32_t item = it * stride + blockIdx.x * kBlock + threadIdx.x;
+    bool mine = item < total;
+    uint32_t p = item;
+    if (SPARSE)
     {
-      const float4 s0 = a.pb.s0[p], s1 = a.pb.s1[p];
-      radiance = vec3{s0.x, s0.y, s0.z};
-      material = vec3{s0.w, s1.x, s1.y};
-      const vec3 nPrev{s1.z, s1.w, rd.w};
-      const uint32_t occl = a.pb.mask[p];
-      // lights of the previous hit, whose position is this ray's origin (CPUScene.cpp:31-49, in that order)
-      for (uint32_t l = 0; l < a.lights->numDir; ++l)
-      {
-        const rthip_dir_light& L = a.lights->dir[l];
-        if (!((occl >> l) & 1u))
-          radiance = radiance + rtd::brdfEvaluate(albedo, nPrev, vec3{-L.direction[0], -L.direction[1], -L.direction[2]},
-                                                  vec3{L.color[0], L.color[1], L.color[2]});
-      }
-      for (uint32_t l = 0; l < a.lights->numPoint; ++l)
-      {
-        const rthip_point_light& L = a.lights->point[l];
-        const vec3 lightDir = vec3{L.position[0], L.position[1], L.position[2]} - o;
-        const float dist = rt::length(lightDir);
-        const float illuminance = rt::maxRef(1 - dist / L.attenuation, 0.0f);
-        radiance = radiance + illuminance * rtd::brdfEvaluate(albedo, nPrev, lightDir, vec3{L.color[0], L.color[1], L.color[2]});
-      }
-      if (a.depth - 1 < a.aovDepths)
-        a.aovShadow[((size_t)s * a.aovDepths + (a.depth - 1)) * a.g.numLocalPixels + i] = (uint8_t)occl;
+      if (mine)
+        p = a.list[item];
     }
-    bool finished = a.finalFold != 0;
-    uint32_t rec = RTFLAT_INVALID;
-    float t = FLT_MAX;
-    vec3 rnd{0, 0, 0};
-    if (!finished)
+    else if (mine)
     {
-      const uint2 hv = a.pb.hit[p];
-      t = __uint_as_float(hv.x);
-      rec = hv.y;
-      if (!(t < FLT_MAX)) // CPUScene.cpp:10
-        finished = true;
+      if (a.depth == 0 && a.primaryInRegs)
+      {
+        // no liveness bytes exist yet: every slot is a camera sample unless its pixel is outside the image
+      }
+      else
+        mine = a.pb.live[p] == depthTag;
+    }
+    bool survives = false;
+    if (mine)
+    {
+      uint32_t s, i;
+      sampleOf(a.g, p, s, i);
+      uint32_t w = 0, h = 0;
+      bool havePixel = false;
+      const bool regen = a.depth == 0 && a.primaryInRegs;
+      vec3 o{0, 0, 0}, d{0, 0, 1}, rnd{0, 0, 0};
+      float prevNz = 0.0f;
+      bool valid = true;
+      if (regen)
+      {
+        // slots of pixels outside the image were never traced: their hit records are stale
+        valid = pixelOf(a.g, i, w, h);
+        havePixel = true;
+      }
       else
       {
-        nHits++;
-        uint32_t w, h;
-        pixelOf(a.g, i, w, h);
-        rnd = rtd::rand01(w, h, a.sampBegin + s);
-        const float pr = rt::maxRef(rt::maxRef(albedo.x, albedo.y), albedo.z); // :13
-        if (a.depth > 5)                                                      // :19 (depth >= maxDepth never reaches here)
+        const float4 ro = a.pb.rayO[p], rd = a.pb.rayD[p];
+        o = vec3{ro.x, ro.y, ro.z};
+        d = vec3{rd.x, rd.y, rd.z};
+        prevNz = rd.w;
+      }
+      if (!valid)
+        a.pb.live[p] = kDeadZero;
+      else
+      {
+        vec3 radiance{0.0f, 0.0f, 0.0f}, material{1.0f, 1.0f, 1.0f}; // Ray.h:7-8
+        if (a.depth > 0)
         {
-          if (rnd.z >= pr)
+          const float4 s0 = a.pb.s0[p], s1 = a.pb.s1[p];
+          radiance = vec3{s0.x, s0.y, s0.z};
+          material = vec3{s0.w, s1.x, s1.y};
+          const vec3 nPrev{s1.z, s1.w, prevNz};
+          const uint32_t occl = a.lights->numDir ? a.pb.mask[p] : 0u;
+          // lights of the previous hit, whose position is this ray's origin (CPUScene.cpp:31-49, in that order)
+          for (uint32_t l = 0; l < a.lights->numDir; ++l)
+          {
+            const rthip_dir_light& L = a.lights->dir[l];
+            if (!((occl >> l) & 1u))
+              radiance = radiance + rtd::brdfEvaluate(albedo, nPrev, vec3{-L.direction[0], -L.direction[1], -L.direction[2]},
+                                                      vec3{L.color[0], L.color[1], L.color[2]});
+          }
+          for (uint32_t l = 0; l < a.lights->numPoint; ++l)
+          {
+            const rthip_point_light& L = a.lights->point[l];
+            const vec3 lightDir = vec3{L.position[0], L.position[1], L.position[2]} - o;
+            const float dist = rt::length(lightDir);
+            const float illuminance = rt::maxRef(1 - dist / L.attenuation, 0.0f);
+            radiance = radiance + illuminance * rtd::brdfEvaluate(albedo, nPrev, lightDir, vec3{L.color[0], L.color[1], L.color[2]});
+          }
+          if (a.depth - 1 < a.aovDepths)
+            a.aovShadow[((size_t)s * a.aovDepths + (a.depth - 1)) * a.g.numLocalPixels + i] = (uint8_t)occl;
+        }
+        bool finished = a.finalFold != 0;
+        uint32_t rec = RTFLAT_INVALID;
+        float t = FLT_MAX;
+        if (!finished)
+        {
+          const uint2 hv = a.pb.hit[p];
+          t = __uint_as_float(hv.x);
+          rec = hv.y;
+          if (!(t < FLT_MAX)) // CPUScene.cpp:10
             finished = true;
           else
-            material = material / pr;
+          {
+            nHits++;
+            if (!havePixel)
+              pixelOf(a.g, i, w, h);
+            rnd = rtd::rand01(w, h, a.sampBegin + s);
+            if (regen) // the primary ray was never stored: same function, same bits (only paths that hit need it)
+              rtd::primaryRay(*a.cam, a.g.width, a.g.height, w, h, a.sampBegin + s, rnd, o, d);
+            const float pr = rt::maxRef(rt::maxRef(albedo.x, albedo.y), albedo.z); // :13
+            if (a.depth > 5)                                                      // :19 (depth >= maxDepth never reaches here)
+            {
+              if (rnd.z >= pr)
+                finished = true;
+              else
+                material = material / pr;
+            }
+          }
+        }
+        if (finished)
+        {
+          if (a.depth == 0)
+            a.pb.live[p] = kDeadZero; // a primary miss adds exactly +0 to the accumulator: nothing to store
+          else
+          {
+            a.pb.s0[p] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            a.pb.live[p] = kDead;
+          }
+        }
+        else
+        {
+          const float4* tp = reinterpret_cast<const float4*>(a.scene.tris + rec);
+          const float4 a2 = tp[2], a3 = tp[3];
+          const vec3 n{a2.y, a2.z, a2.w};
+          if (a.depth < a.aovDepths)
+            a.aovTri[((size_t)s * a.aovDepths + a.depth) * a.g.numLocalPixels + i] = __float_as_uint(a3.x);
+          const float payloadEmissive = a.depth == 0 ? 1.0f : 0.0f;                  // Ray.h:10, CPUScene.cpp:61
+          radiance = radiance + material * emissive * payloadEmissive;              // :27
+          material = material * albedo;                                             // :28
+          const vec3 position = o + d * t;                                          // :238
+          const vec3 normalLight = rt::dot(n, d) < 0 ? n : -n;                      // :240
+          vec3 nd{0.0f, 0.0f, 0.0f};
+          if (a.depth + 1 < a.maxDepth) // the bounce ray of the last shaded depth is never traced
+            nd = rtd::bounceDirection(normalLight, rnd);                            // :54-60
+          a.pb.rayO[p] = make_float4(position.x, position.y, position.z, 0.0f);
+          a.pb.rayD[p] = make_float4(nd.x, nd.y, nd.z, n.z);
+          a.pb.s0[p] = make_float4(radiance.x, radiance.y, radiance.z, material.x);
+          a.pb.s1[p] = make_float4(material.y, material.z, n.x, n.y);
+          a.pb.live[p] = (uint8_t)(a.depth + 1);
+          nAlive++;
+          survives = true;
         }
       }
     }
-    if (finished)
+    if (SPARSE)
     {
-      a.pb.s0[p] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-      a.pb.live[p] = kDead;
-      continue;
+      // append the survivors to the next depth's slot list: one atomic per wave, ranks from the ballot
+      const uint64_t m = __ballot(survives);
+      if (m)
+      {
+        uint32_t base = 0;
+        if (laneId() == (uint32_t)__ffsll((long long)m) - 1)
+          base = atomicAdd(&a.counters->listCount[a.depth + 1], (uint32_t)__popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1);
+        if (survives)
+          a.listNext[base + rankIn(m)] = p;
+      }
     }
-    const float4* tp = reinterpret_cast<const float4*>(a.scene.tris + rec);
-    const float4 a2 = tp[2], a3 = tp[3];
-    const vec3 n{a2.y, a2.z, a2.w};
-    if (a.depth < a.aovDepths)
-      a.aovTri[((size_t)s * a.aovDepths + a.depth) * a.g.numLocalPixels + i] = __float_as_uint(a3.x);
-    const float payloadEmissive = a.depth == 0 ? 1.0f : 0.0f;                  // Ray.h:10, CPUScene.cpp:61
-    radiance = radiance + material * emissive * payloadEmissive;              // :27
-    material = material * albedo;                                             // :28
-    const vec3 position = o + d * t;                                          // :238
-    const vec3 normalLight = rt::dot(n, d) < 0 ? n : -n;                      // :240
-    const vec3 nd = rtd::bounceDirection(normalLight, rnd);                   // :54-60
-    a.pb.rayO[p] = make_float4(position.x, position.y, position.z, 0.0f);
-    a.pb.rayD[p] = make_float4(nd.x, nd.y, nd.z, n.z);
-    a.pb.s0[p] = make_float4(radiance.x, radiance.y, radiance.z, material.x);
-    a.pb.s1[p] = make_float4(material.y, material.z, n.x, n.y);
-    a.pb.live[p] = (uint8_t)(a.depth + 1);
-    nAlive++;
   }
   // block tallies: one atomic per block and counter
   for (int off = 32; off > 0; off >>= 1)
@@ -631,29 +758,92 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
   }
 }
 
+// dense -> sparse hand-over: collects the slots alive at `depth` into a list (order: ascending slot within a
+// block's 4096-slot span, spans in arrival order).  One atomic per block.
+__global__ __launch_bounds__(kBlock) void k_compact(PathBuffers pb, uint32_t numSlots, uint32_t depth, uint32_t* list, uint32_t capacity,
+                                                    DeviceCounters* counters)
+{
+  __shared__ uint32_t sWave[kWavesPerBlock];
+  __shared__ uint32_t sBase;
+  const uint32_t lane = laneId(), wv = threadIdx.x >> 6;
+  const uint32_t spanBase = blockIdx.x * (kBlock * 16) + threadIdx.x * 16;
+  uint32_t bits = 0, cnt = 0;
+  if (spanBase < numSlots) // numSlots is a multiple of 64, the buffer is padded: the 16-byte load stays in bounds
+  {
+    const uint4 v = *reinterpret_cast<const uint4*>(pb.live + spanBase);
+    const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (spanBase + k < numSlots && ((wds[k >> 2] >> ((k & 3) * 8)) & 0xffu) == depth)
+      {
+        bits |= 1u << k;
+        cnt++;
+      }
+  }
+  // exclusive prefix of cnt over the wave, then over the block
+  uint32_t incl = cnt;
+  for (int off = 1; off < 64; off <<= 1)
+  {
+    const uint32_t up = __shfl_up(incl, off);
+    if ((int)lane >= off)
+      incl += up;
+  }
+  if (lane == 63)
+    sWave[wv] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    uint32_t tot = 0;
+    for (uint32_t k = 0; k < kWavesPerBlock; ++k)
+    {
+      const uint32_t c = sWave[k];
+      sWave[k] = tot;
+      tot += c;
+    }
+    sBase = tot ? atomicAdd(&counters->listCount[depth], tot) : 0u;
+  }
+  __syncthreads();
+  uint32_t dst = sBase + sWave[wv] + (incl - cnt);
+  for (int k = 0; k < 16; ++k)
+    if ((bits >> k) & 1u)
+    {
+      if (dst < capacity)
+        list[dst] = spanBase + k;
+      dst++;
+    }
+}
+
 // accumulator[pix] += radiance / float(N), sample passes in ascending order (CPURenderer.cpp:197)
 __global__ __launch_bounds__(kBlock) void k_accumulate(FrameGeom g, PathBuffers pb, float* acc, uint32_t numBatchSamples)
 {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= g.numLocalPixels)
     return;
-  if (pb.live[i] != kDead)
-    return; // cannot happen once the pipeline has drained; never add garbage
-  uint32_t w, h;
-  if (!pixelOf(g, i, w, h))
-    return;
-  float r = acc[3 * (size_t)i], gg = acc[3 * (size_t)i + 1], b = acc[3 * (size_t)i + 2];
+  float r = 0, gg = 0, b = 0;
+  bool loaded = false;
   const float n = float(g.numSamples);
   for (uint32_t s = 0; s < numBatchSamples; ++s)
   {
-    const float4 v = pb.s0[(size_t)s * g.numLocalPixels + i];
+    const size_t p = (size_t)s * g.numLocalPixels + i;
+    // kDeadZero: the sample's radiance is exactly +0 (primary miss) -> adding 0/N leaves the sum unchanged
+    if (pb.live[p] != kDead)
+      continue;
+    if (!loaded)
+    {
+      r = acc[3 * (size_t)i], gg = acc[3 * (size_t)i + 1], b = acc[3 * (size_t)i + 2];
+      loaded = true;
+    }
+    const float4 v = pb.s0[p];
     r += v.x / n;
     gg += v.y / n;
     b += v.z / n;
   }
-  acc[3 * (size_t)i] = r;
-  acc[3 * (size_t)i + 1] = gg;
-  acc[3 * (size_t)i + 2] = b;
+  if (loaded)
+  {
+    acc[3 * (size_t)i] = r;
+    acc[3 * (size_t)i + 1] = gg;
+    acc[3 * (size_t)i + 2] = b;
+  }
 }
 
 // image = pow(max(accumulator * resolver, 0), 0.45)  (CPURenderer.cpp:196,198); display only
@@ -790,14 +980,17 @@ struct rthip_ctx
   DevBuf<float> acc, img, rowScratch;
   DevBuf<uint32_t> aovTri;
   DevBuf<uint8_t> aovShadow;
-  DevBuf<uint32_t> fetch; // one work-fetch counter per traversal launch of a batch
   DevBuf<uint32_t> spill;
+  DevBuf<uint32_t> listA, listB; // sparse-mode slot lists (even / odd depth)
+  uint32_t spillCap = 1;         // per-lane spill entries the uploaded BVH can need
+  uint32_t sparseCap = 0;        // capacity of listA / listB
+  bool fusedPrimary = true;      // generate rays inside the depth-0 traversal kernel instead of storing them
   DevBuf<DeviceCounters> counters;
   uint32_t lastBatchBegin = 0, lastBatchCount = 0, lastSamp = 0;
   bool renderedAny = false;
   bool countWork = false, kernelTiming = false;
-  float kernelMs[5] = {};
-  uint32_t kernelLaunches[5] = {};
+  float kernelMs[6] = {};
+  uint32_t kernelLaunches[6] = {};
   rthip_counters totals{};
 };
 
@@ -844,37 +1037,61 @@ struct KernelTimer
   }
 };
 
+// grid of a traversal launch over `total` work items: one run of runLen items per wave, runs sized so that the
+// chip (numCUs x 8 blocks) is covered several times over when there is enough work
+void traceGeometry(const rthip_ctx* c, uint32_t total, uint32_t& blocks, uint32_t& runLen)
+{
+  const uint32_t wavesWanted = (uint32_t)c->numCUs * 8u * kWavesPerBlock * 4u;
+  uint32_t rl = (total + wavesWanted - 1) / wavesWanted;
+  rl = ((rl + 63u) / 64u) * 64u;
+  runLen = std::max(64u, std::min(rl, kMaxRun));
+  const uint32_t waves = (total + runLen - 1) / runLen;
+  blocks = std::max(1u, (waves + kWavesPerBlock - 1) / kWavesPerBlock);
+}
+
 int ensurePathBuffers(rthip_ctx* c, size_t numSlots)
 {
   int rc;
   if ((rc = c->rayO.ensure(numSlots)) || (rc = c->rayD.ensure(numSlots)) || (rc = c->s0.ensure(numSlots)) || (rc = c->s1.ensure(numSlots)) ||
       (rc = c->hit.ensure(numSlots)) || (rc = c->live.ensure(numSlots + 64)) || (rc = c->mask.ensure(numSlots)))
     return rc;
-  if ((rc = c->spill.ensure((size_t)kSpillCap * c->traceBlocks * kBlock)))
+  uint32_t blocks, runLen;
+  traceGeometry(c, (uint32_t)numSlots, blocks, runLen);
+  if ((rc = c->spill.ensure((size_t)c->spillCap * blocks * kBlock)))
     return rc;
-  if ((rc = c->fetch.ensure(2 * kMaxDepthSlots + 8)))
+  c->sparseCap = (uint32_t)std::max<size_t>(4096, numSlots / 32);
+  if ((rc = c->listA.ensure(c->sparseCap)) || (rc = c->listB.ensure(c->sparseCap)))
     return rc;
   return c->counters.ensure(1);
 }
 
+// list == nullptr: dense launch over all numSlots slots; otherwise sparse launch over the device-side list whose
+// length is at most `bound`
 template <int MODE>
-int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t fetchIndex, float tmin, float tmax)
+int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBegin, float tmin, float tmax, const uint32_t* list = nullptr,
+                uint32_t bound = 0)
 {
   TraceArgs a;
   a.scene = devScene(c);
   a.pb = pathBuffers(c);
   a.lights = c->lights.p;
+  a.geom = c->geom;
+  a.cam = c->camConsts.p;
+  a.sampBegin = sampBegin;
   a.numSlots = numSlots;
+  a.list = list;
+  a.listCount = list ? &c->counters.p->listCount[depth] : nullptr;
   a.depth = depth;
-  a.fetchCounter = c->fetch.p + fetchIndex;
   a.spill = c->spill.p;
   a.counters = c->counters.p;
   a.tmin = tmin;
   a.tmax = tmax;
   a.anyOut = c->anyOut.p;
-  const uint32_t chunks = (numSlots + kChunk - 1) / kChunk;
-  const uint32_t blocks = std::max(1u, std::min(c->traceBlocks, (chunks + kWavesPerBlock - 1) / kWavesPerBlock));
-  KernelTimer kt(c, MODE == CLOSEST ? 1 : 3);
+  uint32_t blocks;
+  traceGeometry(c, list ? bound : numSlots, blocks, a.runLen);
+  if ((size_t)c->spillCap * blocks * kBlock > c->spill.n)
+    return RTHIP_E_LIMIT;
+  KernelTimer kt(c, (MODE == CLOSEST || MODE == PRIMARY) ? 1 : 3);
   if (c->countWork)
     hipLaunchKernelGGL((k_trace<MODE, true>), dim3(blocks), dim3(kBlock), 0, c->stream, a);
   else
@@ -897,18 +1114,19 @@ void addCounters(rthip_counters& dst, const DeviceCounters& s)
 }
 
 // one batch of `count` sample passes starting at sampBegin
-int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, bool allowHostPolls)
+int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count)
 {
   const uint32_t P = c->geom.numLocalPixels;
   const uint32_t numSlots = P * count;
-  const uint32_t shadeBlocks = std::max(1u, std::min((numSlots + kBlock - 1) / kBlock, (uint32_t)c->numCUs * 8u));
-  HIPCHK(hipMemsetAsync(c->fetch.p, 0, c->fetch.n * sizeof(uint32_t), c->stream));
+  const uint32_t shadeBlocksDense = std::max(1u, std::min((numSlots + kBlock - 1) / kBlock, (uint32_t)c->numCUs * 8u));
   HIPCHK(hipMemsetAsync(c->counters.p, 0, sizeof(DeviceCounters), c->stream));
   if (c->aovDepths)
   {
     HIPCHK(hipMemsetAsync(c->aovTri.p, 0xff, (size_t)count * c->aovDepths * P * sizeof(uint32_t), c->stream));
     HIPCHK(hipMemsetAsync(c->aovShadow.p, 0xff, (size_t)count * c->aovDepths * P, c->stream));
   }
+  const bool fused = c->fusedPrimary;
+  if (!fused)
   {
     KernelTimer kt(c, 0);
     hipLaunchKernelGGL(k_generate, dim3((numSlots + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->geom, c->camConsts.p, pathBuffers(c),
@@ -916,55 +1134,75 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, bool allowHost
     HIPCHK(hipGetLastError());
   }
   const bool haveDirLights = c->hostLights.numDir > 0;
-  uint32_t fetchIndex = 0;
   ShadeArgs sa;
   sa.g = c->geom;
   sa.scene = devScene(c);
   sa.pb = pathBuffers(c);
   sa.lights = c->lights.p;
+  sa.cam = c->camConsts.p;
   sa.counters = c->counters.p;
   sa.numSlots = numSlots;
   sa.maxDepth = c->maxDepth;
   sa.sampBegin = sampBegin;
+  sa.primaryInRegs = fused ? 1u : 0u;
   sa.aovDepths = c->aovDepths;
   sa.aovTri = c->aovTri.p;
   sa.aovShadow = c->aovShadow.p;
   const float tmin = 1e-4f, tmax = 1e20f; // CPURenderer.cpp:194, CPUScene.cpp:34 (double literals narrowed to float)
-  uint32_t d = 0;
-  for (;; ++d)
+  bool sparse = false;
+  uint32_t bound = numSlots; // upper bound of the paths alive at the current depth
+  for (uint32_t d = 0;; ++d)
   {
     const bool last = d == c->maxDepth;
-    if (d > 0 && haveDirLights)
-    {
-      int rc = launchTrace<SHADOW>(c, numSlots, d, fetchIndex++, tmin, tmax);
-      if (rc)
-        return rc;
-    }
-    else if (d > 0)
-      HIPCHK(hipMemsetAsync(c->mask.p, 0, numSlots, c->stream));
+    const uint32_t* list = sparse ? ((d & 1u) ? c->listB.p : c->listA.p) : nullptr;
+    uint32_t* listNext = (d & 1u) ? c->listA.p : c->listB.p;
+    int rc;
+    if (d > 0 && haveDirLights && (rc = launchTrace<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, bound)))
+      return rc;
     if (!last)
     {
-      int rc = launchTrace<CLOSEST>(c, numSlots, d, fetchIndex++, tmin, tmax);
+      if (d == 0 && fused)
+        rc = launchTrace<PRIMARY>(c, numSlots, 0, sampBegin, tmin, tmax);
+      else
+        rc = launchTrace<CLOSEST>(c, numSlots, d, sampBegin, tmin, tmax, list, bound);
       if (rc)
         return rc;
     }
     sa.depth = d;
     sa.finalFold = last ? 1u : 0u;
+    sa.list = list;
+    sa.listNext = listNext;
     {
       KernelTimer kt(c, 2);
-      hipLaunchKernelGGL(k_shade, dim3(shadeBlocks), dim3(kBlock), 0, c->stream, sa);
+      if (sparse)
+      {
+        const uint32_t blocks = std::max(1u, std::min((bound + kBlock - 1) / kBlock, (uint32_t)c->numCUs * 8u));
+        hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(kBlock), 0, c->stream, sa);
+      }
+      else
+        hipLaunchKernelGGL(k_shade<false>, dim3(shadeBlocksDense), dim3(kBlock), 0, c->stream, sa);
       HIPCHK(hipGetLastError());
     }
     if (last)
       break;
-    if (allowHostPolls && d >= 1)
+    if (!sparse && d + 1 < c->maxDepth)
     {
-      // stop issuing depths once no path is alive (paths end by miss long before the cap in open scenes)
+      // how many paths go on?  stop when none do; switch to slot lists when few do (open scenes lose most paths
+      // within a bounce or two, and scanning every slot's liveness byte for a handful of paths is wasted work)
       unsigned long long alive = 0;
       HIPCHK(hipMemcpyAsync(&alive, &c->counters.p->alive[d + 1], sizeof(alive), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       if (alive == 0)
         break;
+      bound = (uint32_t)alive;
+      if (alive <= c->sparseCap / 2)
+      {
+        KernelTimer kt(c, 5);
+        hipLaunchKernelGGL(k_compact, dim3((numSlots + kBlock * 16 - 1) / (kBlock * 16)), dim3(kBlock), 0, c->stream, pathBuffers(c), numSlots,
+                           d + 1, listNext, c->sparseCap, c->counters.p);
+        HIPCHK(hipGetLastError());
+        sparse = true;
+      }
     }
   }
   {
@@ -999,7 +1237,7 @@ int renderPasses(rthip_ctx* c, uint32_t sampBegin, uint32_t count, bool sync)
   while (done < count)
   {
     const uint32_t n = std::min(c->batchCap, count - done);
-    int rc = renderBatch(c, sampBegin + done, n, true);
+    int rc = renderBatch(c, sampBegin + done, n);
     if (rc)
       return rc;
     rc = foldCounters(c); // also drains the batch so its path buffers can be reused
@@ -1063,7 +1301,7 @@ int rthip_destroy(rthip_ctx* c)
   c->modelNodes.release(), c->nodes.release(), c->tris.release(), c->lights.release(), c->tileIds.release(), c->camConsts.release();
   c->rayO.release(), c->rayD.release(), c->s0.release(), c->s1.release(), c->hit.release(), c->live.release(), c->mask.release();
   c->anyOut.release(), c->acc.release(), c->img.release(), c->rowScratch.release(), c->aovTri.release(), c->aovShadow.release();
-  c->fetch.release(), c->spill.release(), c->counters.release();
+  c->spill.release(), c->listA.release(), c->listB.release(), c->counters.release();
   (void)hipEventDestroy(c->evA), (void)hipEventDestroy(c->evB), (void)hipEventDestroy(c->evK0), (void)hipEventDestroy(c->evK1);
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1081,7 +1319,7 @@ int rthip_upload_scene(rthip_ctx* c, const rtflat_info* info, const rtflat_model
   if (numDirLights > kMaxLights || numPointLights > kMaxLights || info->numTris >= (1u << 28) - 1u)
     return RTHIP_E_LIMIT;
   // the per-lane stack must hold the deepest root-to-leaf chain of far children
-  if (info->maxDepthBlas + 2 > kStackLds + kSpillCap)
+  if (info->maxDepthBlas + 2 > kMaxStack)
     return RTHIP_E_LIMIT;
   // host-side shape checks before any kernel dereferences these indices
   for (uint32_t k = 0; k < info->numModelNodes; ++k)
@@ -1123,6 +1361,8 @@ int rthip_upload_scene(rthip_ctx* c, const rtflat_info* info, const rtflat_model
     L.point[i] = pointLights[i];
   HIPCHK(hipMemcpy(c->lights.p, &L, sizeof(L), hipMemcpyHostToDevice));
   c->info = *info;
+  c->spillCap = info->maxDepthBlas + 2 > kStackLds ? info->maxDepthBlas + 2 - kStackLds : 1u;
+  c->spill.release(); // sized per scene in ensurePathBuffers
   c->haveScene = true;
   c->haveFrame = false;
   return 0;
@@ -1137,8 +1377,8 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
   if (f->maxDepth == 0 || f->maxDepth > kMaxDepthSlots || f->maxDepth > 254)
     return RTHIP_E_LIMIT;
   const uint32_t ts = f->tileSize ? f->tileSize : 64u;
-  if (ts % 8u)
-    return RTHIP_E_ARG;
+  if (ts < 8u || (ts & (ts - 1u)) || f->width > 65535u || f->height > 65535u)
+    return RTHIP_E_ARG; // tiles are powers of two >= 8; tile origins are packed into 16 bits each
   // the padding of the BVH boxes was sized for ray origins within originBound of the scene centre
   {
     float d2 = 0;
@@ -1179,8 +1419,15 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
   int rc;
   if ((rc = c->tileIds.ensure(g.numLocalTiles)))
     return rc;
-  HIPCHK(hipMemcpy(c->tileIds.p, c->hostTileIds.data(), sizeof(uint32_t) * g.numLocalTiles, hipMemcpyHostToDevice));
-  g.tileIds = c->tileIds.p;
+  {
+    std::vector<uint32_t> xy(g.numLocalTiles);
+    for (uint32_t k = 0; k < g.numLocalTiles; ++k)
+      xy[k] = ((c->hostTileIds[k] % tilesX) * ts) | (((c->hostTileIds[k] / tilesX) * ts) << 16);
+    HIPCHK(hipMemcpy(c->tileIds.p, xy.data(), sizeof(uint32_t) * g.numLocalTiles, hipMemcpyHostToDevice));
+  }
+  g.tileXY = c->tileIds.p;
+  g.tileShift = (uint32_t)__builtin_ctz(ts);
+  g.sampleMagic = g.numLocalTiles > 1 ? (uint32_t)(((1ull << 32) + g.numLocalTiles - 1) / g.numLocalTiles) : 0u;
   c->geom = g;
   c->camera = *camera;
   c->maxDepth = f->maxDepth;
@@ -1190,6 +1437,11 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
   c->batchCap = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(f->numSamples, pathCap / P64));
   if (c->aovDepths)
     c->batchCap = std::min(c->batchCap, 4u);
+  // sampleOf's multiply-high division is exact while (batch * tiles) * tiles < 2^32
+  while (c->batchCap > 1 && (uint64_t)c->batchCap * g.numLocalTiles * g.numLocalTiles >= (1ull << 32))
+    c->batchCap--;
+  if ((uint64_t)c->batchCap * g.numLocalTiles * g.numLocalTiles >= (1ull << 32))
+    return RTHIP_E_LIMIT;
   const size_t numSlots = (size_t)P64 * c->batchCap;
   if ((rc = ensurePathBuffers(c, numSlots)) || (rc = c->acc.ensure(P64 * 3)) || (rc = c->img.ensure(P64 * 3)) || (rc = c->camConsts.ensure(1)))
     return rc;
@@ -1363,9 +1615,14 @@ int rthip_untile(rthip_ctx* c, const float* tileMajorDev, const uint32_t* tileId
   int rc = ids.ensure(numTiles);
   if (rc)
     return rc;
-  HIPCHK(hipMemcpy(ids.p, tileIds, sizeof(uint32_t) * numTiles, hipMemcpyHostToDevice));
+  {
+    std::vector<uint32_t> xy(numTiles);
+    for (uint32_t k = 0; k < numTiles; ++k)
+      xy[k] = ((tileIds[k] % c->geom.tilesX) * ts) | (((tileIds[k] / c->geom.tilesX) * ts) << 16);
+    HIPCHK(hipMemcpy(ids.p, xy.data(), sizeof(uint32_t) * numTiles, hipMemcpyHostToDevice));
+  }
   FrameGeom g = c->geom;
-  g.tileIds = ids.p;
+  g.tileXY = ids.p;
   g.numLocalTiles = numTiles;
   g.numLocalPixels = numTiles * ts * ts;
   hipLaunchKernelGGL(k_untile, dim3((g.numLocalPixels + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, g, tileMajorDev, rowMajorDev,
@@ -1392,6 +1649,14 @@ int rthip_set_work_counting(rthip_ctx* c, int enabled)
   return 0;
 }
 
+int rthip_set_fused_primary(rthip_ctx* c, int enabled)
+{
+  if (!c)
+    return RTHIP_E_ARG;
+  c->fusedPrimary = enabled != 0;
+  return 0;
+}
+
 int rthip_set_kernel_timing(rthip_ctx* c, int enabled)
 {
   if (!c)
@@ -1400,11 +1665,11 @@ int rthip_set_kernel_timing(rthip_ctx* c, int enabled)
   return 0;
 }
 
-int rthip_get_kernel_times(rthip_ctx* c, float msOut[5], uint32_t launchesOut[5])
+int rthip_get_kernel_times(rthip_ctx* c, float msOut[6], uint32_t launchesOut[6])
 {
   if (!c || !msOut || !launchesOut)
     return RTHIP_E_ARG;
-  for (int i = 0; i < 5; ++i)
+  for (int i = 0; i < 6; ++i)
   {
     msOut[i] = c->kernelMs[i];
     launchesOut[i] = c->kernelLaunches[i];
@@ -1512,11 +1777,10 @@ int rthip_probe_trace(rthip_ctx* c, const float* origin3, const float* dir3, uin
     return rc;
   HIPCHK(hipMemcpy(o.p, origin3, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d.p, dir3, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-  HIPCHK(hipMemsetAsync(c->fetch.p, 0, c->fetch.n * sizeof(uint32_t), c->stream));
   HIPCHK(hipMemsetAsync(c->counters.p, 0, sizeof(DeviceCounters), c->stream));
   hipLaunchKernelGGL(k_probe_pack, dim3((n + 255) / 256), dim3(256), 0, c->stream, o.p, d.p, n, c->rayO.p, c->rayD.p, c->live.p);
   HIPCHK(hipGetLastError());
-  if ((rc = launchTrace<CLOSEST>(c, n, 0, 0, tmin, tmax)) || (rc = launchTrace<ANYPROBE>(c, n, 0, 1, tmin, tmax)))
+  if ((rc = launchTrace<CLOSEST>(c, n, 0, 0, tmin, tmax)) || (rc = launchTrace<ANYPROBE>(c, n, 0, 0, tmin, tmax)))
     return rc;
   hipLaunchKernelGGL(k_probe_unpack, dim3((n + 255) / 256), dim3(256), 0, c->stream, devScene(c), c->hit.p, n, id.p, t.p);
   HIPCHK(hipGetLastError());

@@ -177,6 +177,8 @@ int rt_set_option(rt_renderer* r, const char* name, double value)
     fo.originBoundScale = (float)value;
   else if (n == "countWork")
     return r->hip->context() ? rthip_set_work_counting(r->hip->context(), value != 0) : RTHIP_E_NODEVICE;
+  else if (n == "fusedPrimary")
+    return r->hip->context() ? rthip_set_fused_primary(r->hip->context(), value != 0) : RTHIP_E_NODEVICE;
   else if (n == "kernelTiming")
     return r->hip->context() ? rthip_set_kernel_timing(r->hip->context(), value != 0) : RTHIP_E_NODEVICE;
   else
@@ -262,7 +264,7 @@ int rt_get_counters(rt_renderer* r, rthip_counters* out)
     return RTHIP_E_ARG;
   return r->hip->context() ? rthip_get_counters(r->hip->context(), out) : RTHIP_E_NODEVICE;
 }
-int rt_get_kernel_times(rt_renderer* r, float msOut[5], uint32_t launchesOut[5])
+int rt_get_kernel_times(rt_renderer* r, float msOut[6], uint32_t launchesOut[6])
 {
   if (!r)
     return RTHIP_E_ARG;
