@@ -334,7 +334,8 @@ class Renderer:
             buf = (C.c_char * (64 * count)).from_address(ptr.value)
             return np.frombuffer(buf, dtype=dtype, count=count)
 
-        return dict(info=i, info_bytes=bytes(C.string_at(C.addressof(i), C.sizeof(FlatInfo))),
+        # the views alias memory owned by the renderer: keep it alive for as long as the dict lives
+        return dict(_owner=self, info=i, info_bytes=bytes(C.string_at(C.addressof(i), C.sizeof(FlatInfo))),
                     model_nodes=view(mn, i.numModelNodes, MODEL_NODE_DTYPE), nodes=view(nd, max(i.numNodes, 1), NODE_DTYPE),
                     tris=view(tr, max(i.numTris, 1), TRI_DTYPE), build_seconds=secs.value)
 

@@ -220,6 +220,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
 
   // per-lane ray state
   bool active = false;
+  bool groupValid = false; // PRIMARY: this lane carries a camera sample of the current group
   uint32_t slot = 0;
   vec3 o{0, 0, 0}, d{0, 0, 1}, invD{0, 0, 0}, oi{0, 0, 0};
   float best = FLT_MAX, cull = FLT_MAX;
@@ -233,61 +234,80 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
 
   for (;;)
   {
-    // ---------------- work list: scan + compact the next chunk of the run when the list has run dry
-    const uint64_t idleMask = __ballot(!active);
-    const uint32_t numIdle = __popcll(idleMask);
-    if (listNext >= listCount && runNext < runEnd && numIdle >= kRefillThreshold)
+    if (MODE == PRIMARY)
     {
-      const uint32_t chunkEnd = min(runEnd, runNext + kChunk);
-      uint32_t n = 0;
-      for (uint32_t base = runNext; base < chunkEnd; base += 64)
+      // ---------------- primary rays are coherent: take the run 64 slots (one 8x8 pixel block) at a time, generate the
+      // rays in registers at full occupancy, traverse until the whole group is done, store the 64 hit records together
+      if (__ballot(active) == 0)
       {
-        const uint32_t item = base + lane;
-        bool isLive = item < chunkEnd;
-        uint32_t s = item;
-        if (sparse)
+        if (groupValid)
+          a.pb.hit[slot] = make_uint2(__float_as_uint(best), bestRec);
+        groupValid = false;
+        if (runNext >= runEnd)
+          break;
+        slot = runNext + lane;
+        runNext += 64;
+        uint32_t sidx, i, w, h;
+        sampleOf(a.geom, slot, sidx, i);
+        if (slot < runEnd && pixelOf(a.geom, i, w, h))
         {
-          if (isLive)
-            s = a.list[item];
-        }
-        else if (MODE == PRIMARY)
-        {
-          // every slot of a primary launch carries a camera sample unless its pixel lies outside the image
-          uint32_t sidx, i, w, h;
-          sampleOf(a.geom, item, sidx, i);
-          isLive = isLive && pixelOf(a.geom, i, w, h);
-        }
-        else
-          isLive = isLive && (a.pb.live[item] == (uint8_t)a.depth);
-        const uint64_t m = __ballot(isLive);
-        if (isLive)
-          list[n + rankIn(m)] = s;
-        n += __popcll(m);
-      }
-      runNext = chunkEnd;
-      listCount = n;
-      listNext = 0;
-      // the list is written and read by this wave only; LDS operations of one wave complete in order
-    }
-    // ---------------- hand list entries to idle lanes (ballot + mbcnt compaction)
-    const uint32_t avail = listCount - listNext;
-    if (avail > 0 && (numIdle >= kRefillThreshold || numIdle == 64))
-    {
-      const uint32_t r = rankIn(idleMask);
-      const bool take = !active && r < avail;
-      if (take)
-      {
-        slot = list[listNext + r];
-        if (MODE == PRIMARY)
-        {
-          uint32_t sidx, i, w, h;
-          sampleOf(a.geom, slot, sidx, i);
-          pixelOf(a.geom, i, w, h);
           const uint32_t samp = a.sampBegin + sidx;
           rtd::primaryRay(*a.cam, a.geom.width, a.geom.height, w, h, samp, rtd::rand01(w, h, samp), o, d);
+          invD = rtd::padInvDir(d);
+          oi = o * invD;
+          best = FLT_MAX;
+          cull = FLT_MAX;
+          bestRec = RTFLAT_INVALID;
+          cur = RTFLAT_INVALID;
+          mk = 0;
+          sp = spLo = 0;
+          active = true;
+          groupValid = true;
+          nRays++;
         }
-        else
+        continue;
+      }
+    }
+    else
+    {
+      // ---------------- work list: scan + compact the next chunk of the run when the list has run dry
+      const uint64_t idleMask = __ballot(!active);
+      const uint32_t numIdle = __popcll(idleMask);
+      if (listNext >= listCount && runNext < runEnd && numIdle >= kRefillThreshold)
+      {
+        const uint32_t chunkEnd = min(runEnd, runNext + kChunk);
+        uint32_t n = 0;
+        for (uint32_t base = runNext; base < chunkEnd; base += 64)
         {
+          const uint32_t item = base + lane;
+          bool isLive = item < chunkEnd;
+          uint32_t s = item;
+          if (sparse)
+          {
+            if (isLive)
+              s = a.list[item];
+          }
+          else
+            isLive = isLive && (a.pb.live[item] == (uint8_t)a.depth);
+          const uint64_t m = __ballot(isLive);
+          if (isLive)
+            list[n + rankIn(m)] = s;
+          n += __popcll(m);
+        }
+        runNext = chunkEnd;
+        listCount = n;
+        listNext = 0;
+        // the list is written and read by this wave only; LDS operations of one wave complete in order
+      }
+      // ---------------- hand list entries to idle lanes (ballot + mbcnt compaction)
+      const uint32_t avail = listCount - listNext;
+      if (avail > 0 && (numIdle >= kRefillThreshold || numIdle == 64))
+      {
+        const uint32_t r = rankIn(idleMask);
+        const bool take = !active && r < avail;
+        if (take)
+        {
+          slot = list[listNext + r];
           const float4 ro = a.pb.rayO[slot];
           o = vec3{ro.x, ro.y, ro.z};
           if (MODE == SHADOW)
@@ -302,25 +322,25 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
             const float4 rd = a.pb.rayD[slot];
             d = vec3{rd.x, rd.y, rd.z};
           }
+          invD = rtd::padInvDir(d);
+          oi = o * invD;
+          best = FLT_MAX;
+          cull = FLT_MAX;
+          bestRec = RTFLAT_INVALID;
+          cur = RTFLAT_INVALID;
+          mk = 0;
+          sp = spLo = 0;
+          active = true;
+          nRays++;
         }
-        invD = rtd::padInvDir(d);
-        oi = o * invD;
-        best = FLT_MAX;
-        cull = FLT_MAX;
-        bestRec = RTFLAT_INVALID;
-        cur = RTFLAT_INVALID;
-        mk = 0;
-        sp = spLo = 0;
-        active = true;
-        nRays++;
+        listNext += min(numIdle, avail);
       }
-      listNext += min(numIdle, avail);
-    }
-    if (__ballot(active) == 0)
-    {
-      if (runNext >= runEnd && listNext >= listCount)
-        break;
-      continue;
+      if (__ballot(active) == 0)
+      {
+        if (runNext >= runEnd && listNext >= listCount)
+          break;
+        continue;
+      }
     }
 
     // ---------------- inner nodes: descend until this lane holds a leaf (or its ray is finished)
@@ -369,10 +389,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
             else
               a.pb.mask[slot] = (uint8_t)occluded;
           }
-          else if (MODE == CLOSEST || MODE == PRIMARY)
+          else if (MODE == CLOSEST)
             a.pb.hit[slot] = make_uint2(__float_as_uint(best), bestRec);
-          else
+          else if (MODE == ANYPROBE)
             a.anyOut[slot] = 0;
+          // PRIMARY: the group's hit records are stored together once every lane has finished
           if (done)
             active = false;
           continue;
@@ -971,7 +992,7 @@ struct rthip_ctx
   FrameGeom geom{};
   uint32_t maxDepth = 12, aovDepths = 0;
   uint32_t batchCap = 1; // sample passes per launch batch
-  std::vector<uint32_t> hostTileIds;
+  std::vector<uint32_t> hostTileIds, hostTileXY;
   DevBuf<uint32_t> tileIds;
   DevBuf<CameraConsts> camConsts;
   DevBuf<float4> rayO, rayD, s0, s1;
@@ -1417,13 +1438,22 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
     return RTHIP_E_LIMIT;
   g.numLocalPixels = (uint32_t)P64;
   int rc;
-  if ((rc = c->tileIds.ensure(g.numLocalTiles)))
-    return rc;
+  {
+    const uint32_t* before = c->tileIds.p;
+    if ((rc = c->tileIds.ensure(g.numLocalTiles)))
+      return rc;
+    if (c->tileIds.p != before)
+      c->hostTileXY.clear();
+  }
   {
     std::vector<uint32_t> xy(g.numLocalTiles);
     for (uint32_t k = 0; k < g.numLocalTiles; ++k)
       xy[k] = ((c->hostTileIds[k] % tilesX) * ts) | (((c->hostTileIds[k] / tilesX) * ts) << 16);
-    HIPCHK(hipMemcpy(c->tileIds.p, xy.data(), sizeof(uint32_t) * g.numLocalTiles, hipMemcpyHostToDevice));
+    if (xy != c->hostTileXY) // frames of one animation keep their tiling: upload the table only when it changes
+    {
+      HIPCHK(hipMemcpy(c->tileIds.p, xy.data(), sizeof(uint32_t) * g.numLocalTiles, hipMemcpyHostToDevice));
+      c->hostTileXY.swap(xy);
+    }
   }
   g.tileXY = c->tileIds.p;
   g.tileShift = (uint32_t)__builtin_ctz(ts);
@@ -1450,11 +1480,9 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
     if ((rc = c->aovTri.ensure(numSlots * c->aovDepths)) || (rc = c->aovShadow.ensure(numSlots * c->aovDepths)))
       return rc;
   }
-  HIPCHK(hipMemsetAsync(c->acc.p, 0, P64 * 3 * sizeof(float), c->stream));
-  HIPCHK(hipMemsetAsync(c->img.p, 0, P64 * 3 * sizeof(float), c->stream));
+  HIPCHK(hipMemsetAsync(c->acc.p, 0, P64 * 3 * sizeof(float), c->stream)); // CPURenderer.cpp:142-143 (image is made on read)
   hipLaunchKernelGGL(k_camera, dim3(1), dim3(64), 0, c->stream, *camera, c->camConsts.p);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(c->stream));
   std::memset(&c->totals, 0, sizeof(c->totals));
   std::memset(c->kernelMs, 0, sizeof(c->kernelMs));
   std::memset(c->kernelLaunches, 0, sizeof(c->kernelLaunches));

@@ -1,0 +1,76 @@
+"""Multi-process tile sharding on CPU (gloo, world_size 2): the host logic of raytracer_amd/dist.py -- tile ownership, the
+tile-major layout, the gather and the assembly on rank 0 -- with the per-rank rendering done by the CPU oracle (test
+infrastructure standing in for the GPU here).  The assembled frame must equal a single-process render bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from raytracer_amd import dist as rdist
+from tests import scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tile_assignment_covers_every_tile_once():
+    for (w, h, world, ts) in [(1920, 1080, 8, 64), (250, 130, 3, 64), (64, 64, 2, 64), (3840, 2160, 4, 32)]:
+        a = rdist.assign_tiles(w, h, world, ts)
+        tx, ty = rdist.tile_grid(w, h, ts)
+        assert sorted(np.concatenate(a).tolist()) == list(range(tx * ty))
+        assert max(len(x) for x in a) - min(len(x) for x in a) <= 1
+
+
+def test_tile_major_round_trip_with_partial_tiles():
+    rng = np.random.default_rng(0)
+    w, h, ts = 250, 130, 64
+    img = rng.random((h, w, 3), np.float32)
+    a = rdist.assign_tiles(w, h, 3, ts)
+    bufs = [rdist.to_tile_major(img, t, ts) for t in a]
+    for t, b in zip(a, bufs):
+        assert b.shape == (len(t) * ts * ts, 3)
+    back = rdist.assemble(bufs, a, w, h, ts)
+    assert np.array_equal(back, img)
+    # the first 64 entries of a tile are its first 8x8 pixel block, row-major
+    ww, hh, valid = rdist.local_pixel_coords(a[0][:1], w, h, ts)
+    assert list(ww[:9]) == [0, 1, 2, 3, 4, 5, 6, 7, 0] and list(hh[:9]) == [0] * 8 + [1] and ww[64] == 8 and hh[64] == 0
+
+
+def _worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = scenes.cube_scene()
+    W, H, N, ts = 200, 136, 2, 64
+    assignment = rdist.assign_tiles(W, H, world, ts)
+    o = spec.build_oracle()
+    tx, _ = rdist.tile_grid(W, H, ts)
+    frame = np.zeros((H, W, 3), np.float32)
+    for t in assignment[rank]:  # each rank renders only the tiles it owns
+        x0, y0 = int(t % tx) * ts, int(t // tx) * ts
+        r = o.render(spec.oracle_camera(), W, H, N, max_depth=12, window=(x0, y0, min(W, x0 + ts), min(H, y0 + ts)), workers=2)
+        frame[y0:y0 + ts, x0:x0 + ts] = r["accumulator"][y0:y0 + ts, x0:x0 + ts]
+    local = torch.from_numpy(rdist.to_tile_major(frame, assignment[rank], ts))
+    bufs = rdist.gather_tiles(local, assignment, rank, world, dist)
+    if rank == 0:
+        full = rdist.assemble([b.numpy() for b in bufs], assignment, W, H, ts)
+        np.save(out_path, full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_render_equals_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "frame.npy")
+    mp.start_processes(_worker, args=(2, port, out), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out)
+    spec = scenes.cube_scene()
+    want = spec.build_oracle().render(spec.oracle_camera(), 200, 136, 2, max_depth=12, workers=4)["accumulator"]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

@@ -103,3 +103,118 @@ def test_render_matches_oracle_bitexact(name, W, H, N, depth):
     img = r.image()
     np.testing.assert_allclose(img, want["image"], rtol=2e-6, atol=1e-7)
     r.close()
+
+
+def _render(spec, W, H, N, depth, options=None, tiles=None, passes_per_call=None):
+    r = spec.build_product(options=dict(maxDepth=depth, **(options or {})))
+    if tiles is not None:
+        r.set_tiles(tiles)
+    r.begin_frame(spec.product_camera(), W, H, N)
+    step = passes_per_call or N
+    for s in range(0, N, step):
+        r.render_passes(s, min(step, N - s))
+    return r
+
+
+def test_multi_model_with_fixed_edge_indexing_matches_the_fixed_oracle():
+    spec = scenes.multi_model_scene()
+    W, H, N, depth = 160, 128, 2, 6
+    want = spec.build_oracle(fix_edge_offset=True).render(spec.oracle_camera(), W, H, N, max_depth=depth, workers=14)
+    r = _render(spec, W, H, N, depth, options=dict(referenceEdgeIndexing=0))
+    assert np.array_equal(r.accumulator().view(np.uint32), want["accumulator"].view(np.uint32))
+    faithful = spec.build_oracle().render(spec.oracle_camera(), W, H, N, max_depth=depth, workers=14)
+    assert not np.array_equal(faithful["accumulator"], want["accumulator"])  # the two indexings really differ on this scene
+    r.close()
+
+
+def test_unfused_generate_kernel_gives_the_same_bits():
+    spec = scenes.soup_scene(20000, 3, 0.05, lens=True)
+    a = _render(spec, 200, 136, 3, 6)
+    b = _render(spec, 200, 136, 3, 6, options=dict(fusedPrimary=0))
+    assert np.array_equal(a.accumulator().view(np.uint32), b.accumulator().view(np.uint32))
+    assert a.counters() == b.counters()
+    a.close(), b.close()
+
+
+def test_batching_of_sample_passes_does_not_change_the_result():
+    spec = scenes.heightfield_scene(64, 9)
+    a = _render(spec, 192, 128, 5, 8)
+    b = _render(spec, 192, 128, 5, 8, passes_per_call=1)
+    c = _render(spec, 192, 128, 5, 8, passes_per_call=2)
+    assert np.array_equal(a.accumulator().view(np.uint32), b.accumulator().view(np.uint32))
+    assert np.array_equal(a.accumulator().view(np.uint32), c.accumulator().view(np.uint32))
+    for x in (a, b, c):
+        x.close()
+
+
+def test_tile_subsets_assemble_to_the_full_frame():
+    """Two renderers, each owning every other 64x64 tile (what two GPUs would do), reproduce the single-renderer frame
+    bit for bit; pixels of tiles a renderer does not own are left untouched by its read-back."""
+    from raytracer_amd import dist as rdist
+    spec = scenes.bunny_scene()
+    W, H, N, depth = 250, 200, 2, 5
+    full = _render(spec, W, H, N, depth)
+    want = full.accumulator()
+    assignment = rdist.assign_tiles(W, H, 2, 64)
+    frame = np.full((H, W, 3), -1.0, np.float32)
+    total = {"extendPrimary": 0, "shadow": 0}
+    for tiles in assignment:
+        r = _render(spec, W, H, N, depth, tiles=tiles)
+        out = frame.copy()
+        rc = ra.capi.host_lib().rt_read_accumulator(r._h, ra.capi._fp(out))
+        assert rc == 0
+        w, h, valid = rdist.local_pixel_coords(tiles, W, H, 64)
+        owned = np.zeros((H, W), bool)
+        owned[h[valid], w[valid]] = True
+        assert np.all(out[~owned] == frame[~owned])
+        frame[owned] = out[owned]
+        for k in total:
+            total[k] += r.counters()[k]
+        r.close()
+    assert np.array_equal(frame.view(np.uint32), want.view(np.uint32))
+    assert total["extendPrimary"] == full.counters()["extendPrimary"] == W * H * N
+    assert total["shadow"] == full.counters()["shadow"]
+    full.close()
+
+
+def test_probe_trace_matches_oracle_on_random_rays():
+    spec = scenes.soup_scene(20000, 3, 0.05)
+    r = spec.build_product()
+    o = spec.build_oracle()
+    rng = np.random.default_rng(7)
+    n = 4000
+    org = rng.normal(size=(n, 3))
+    org = (2.5 * org / np.linalg.norm(org, axis=1, keepdims=True)).astype(np.float32)
+    tgt = rng.uniform(-0.8, 0.8, size=(n, 3))
+    d = tgt - org
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[:50, 1] = 0.0  # axis-parallel components
+    tri, t, anyh = ra.Probe(r.context).trace(org, d)
+    for k in range(n):
+        wt, tt = o.closest_hit(org[k], d[k])
+        assert tri[k] == wt, k
+        if wt != 0xFFFFFFFF:
+            assert np.float32(tt) == t[k]
+        assert bool(anyh[k]) == o.any_hit(org[k], d[k])
+    r.close()
+
+
+def test_full_size_properties_of_the_benchmark_configuration():
+    """BASELINE configs[1] at full size (1920x1080, 16 spp, primary + shadow): too big for the oracle in a test, so check
+    size-independent properties: ray counts, run-to-run determinism, agreement of the 1080p accumulator with an
+    oracle render of a window of it, and non-negativity."""
+    spec = scenes.cube_scene()
+    W, H, N = 1920, 1080, 16
+    a = _render(spec, W, H, N, 1)
+    acc = a.accumulator()
+    c = a.counters()
+    assert c["extendPrimary"] == W * H * N and c["extendSecondary"] == 0 and c["shadow"] == c["hits"][0] and c["nonFiniteAccepts"] == 0
+    b = _render(spec, W, H, N, 1, passes_per_call=4)
+    assert np.array_equal(acc.view(np.uint32), b.accumulator().view(np.uint32))
+    win = (900, 500, 1028, 564)
+    want = spec.build_oracle().render(spec.oracle_camera(), W, H, N, max_depth=1, window=win, workers=14)["accumulator"]
+    assert np.array_equal(acc[win[1]:win[3], win[0]:win[2]].view(np.uint32), want[win[1]:win[3], win[0]:win[2]].view(np.uint32))
+    assert acc.min() >= 0 and np.isfinite(acc).all()
+    img = a.image()
+    np.testing.assert_allclose(img, np.power(np.maximum(acc, 0), np.float32(0.45)), rtol=3e-6, atol=1e-7)
+    a.close(), b.close()
