@@ -74,9 +74,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # RT_DIST_BACKEND=gloo lets the N>1 code path be rehearsed with several ranks sharing one GPU (RCCL refuses two ranks
+    # on one device); the driver's real runs use nccl (= RCCL over xGMI), one rank per GPU
+    backend = os.environ.get("RT_DIST_BACKEND", "nccl")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+    local_rank = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     n_gpus = max(args.gpus, world) if world > 1 else 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
@@ -106,7 +115,11 @@ def main():
             t0 = time.perf_counter()
             rc = hl.rthip_copy_accumulator_to(ctx, local_buf.data_ptr(), n_local_floats)
             assert rc == 0, ra.capi.error_string(rc)
-            bufs = rdist.gather_tiles(local_buf, assignment, rank, world, dist)
+            if backend == "nccl":
+                bufs = rdist.gather_tiles(local_buf, assignment, rank, world, dist)
+            else:
+                bufs = rdist.gather_tiles(local_buf.cpu(), assignment, rank, world, dist)
+                bufs = [b.to(f"cuda:{local_rank}") for b in bufs] if rank == 0 else None
             if rank == 0:
                 for src, tiles in zip(bufs, assignment):
                     rc = hl.rthip_untile(ctx, src.data_ptr(), ra.capi._up(tiles), len(tiles), full_frame.data_ptr())
@@ -132,7 +145,7 @@ def main():
     cnt = r.counters()  # totals of the LAST frame (begin_frame resets them)
     rays_local = cnt["extendPrimary"] + cnt["extendSecondary"] + cnt["shadow"]
     t = torch.tensor([elapsed, float(rays_local), float(cnt["extendPrimary"]), float(cnt["extendSecondary"]), float(cnt["shadow"])],
-                     dtype=torch.float64, device=f"cuda:{local_rank}")
+                     dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -228,7 +241,7 @@ def main():
            "config": {"workload": wl["name"], "width": width, "height": height, "spp": spp, "max_depth": max_depth,
                       "tris": int(flat["info"].numTris), "bvh_nodes": int(flat["info"].numNodes),
                       "rays_per_step": int(rays_frame), "primary": int(t[2]), "secondary_extend": int(t[3]), "shadow": int(t[4]),
-                      "parallelism": f"tiles64-rr-x{world}" if world > 1 else "single",
+                      "parallelism": f"tiles64-rr-x{world}-{backend}" if world > 1 else "single",
                       "gather_ms": round(float(np.mean(gather_ms)), 4) if gather_ms else None},
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
