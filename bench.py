@@ -194,7 +194,7 @@ def main():
             traffic = tj.get(args.workload, {}).get(dominant)
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": {"extend": "k_trace<CLOSEST>", "shadow": "k_trace<SHADOW>", "generate": "k_generate",
+    roofline = {"bound": "hbm", "kernel": {"extend": "k_trace<PRIMARY|CLOSEST> (extend)", "shadow": "k_trace<SHADOW>", "generate": "k_generate",
                                            "shade": "k_shade", "accumulate": "k_accumulate", "compact": "k_compact"}[dominant],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes[dominant] / max(1, k_launches), 1),

@@ -43,7 +43,10 @@ constexpr uint32_t kChunk = 512;       // work items a wave scans and compacts a
 constexpr uint32_t kStackLds = 16;     // stack entries per lane kept in LDS
 constexpr uint32_t kMaxStack = 96;     // deepest triangle BVH accepted (LDS part + spill)
 constexpr uint32_t kRefillThreshold = 16; // refill once this many lanes are idle (or no lane is active)
-constexpr uint32_t kMaxRun = 1024;     // most work items one wave is handed
+constexpr uint32_t kMaxRun = 1024;     // most work items one wave is handed (static mode)
+constexpr uint32_t kFetchShards = 8;   // one work counter per XCD label (blockIdx % 8): 8x the atomic rate of one word, L2-local ranges
+constexpr uint32_t kFetchStride = 64;  // counters 256 B apart
+constexpr uint32_t kMaxTraceLaunches = 2 * (64 + 2); // two traversal launches per depth, depth <= kMaxDepthSlots
 constexpr uint8_t kDead = 0xff;        // path finished, radiance in s0
 constexpr uint8_t kDeadZero = 0xfe;    // path finished with exactly zero radiance (primary miss) or pixel outside the image
 constexpr uint32_t kMaxLights = 8;
@@ -54,8 +57,11 @@ enum TraceMode
   CLOSEST = 0,  // closest hit of the stored ray (depth >= 1, or depth 0 when primary rays are stored)
   SHADOW = 1,   // any-hit toward every directional light from the stored origin
   ANYPROBE = 2, // any-hit of the stored ray (probe entry point)
-  PRIMARY = 3   // ray generation fused in: the primary ray is computed in registers, never stored
+  PRIMARY = 3,  // ray generation fused in (the primary ray is computed in registers, never stored); dynamic work fetch
+  PRIMARY_GROUP = 4 // the same for tiny scenes: static runs, one 8x8 pixel block at a time, no refilling
 };
+constexpr bool isPrimary(int mode) { return mode == PRIMARY || mode == PRIMARY_GROUP; }
+constexpr bool isClosest(int mode) { return mode == CLOSEST || isPrimary(mode); }
 
 struct DeviceScene
 {
@@ -182,7 +188,9 @@ struct TraceArgs
   uint32_t numSlots;         // dense: S*P work items, item == slot
   const uint32_t* list;      // sparse: work item -> slot; nullptr in dense mode
   const uint32_t* listCount; // sparse: number of work items (device memory)
-  uint32_t runLen;           // work items per wave (multiple of 64, <= kMaxRun)
+  uint32_t runLen;           // static mode: work items per wave (multiple of 64, <= kMaxRun)
+  uint32_t chunkLen;         // dynamic mode: work items per fetch (multiple of 64)
+  uint32_t* fetch;           // dynamic mode: kFetchShards counters, kFetchStride words apart, zeroed before the launch
   uint32_t depth;            // live[] value this launch serves (dense mode filter)
   uint32_t* spill;           // [spillCap][gridLanes]
   DeviceCounters* counters;
@@ -208,12 +216,35 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
   const float4* __restrict__ tris4 = reinterpret_cast<const float4*>(a.scene.tris);
   const uint32_t numModelNodes = a.scene.numModelNodes;
 
-  // this wave's run of work items
+  // work distribution
+  //  static mode (chunkLen == 0): wave `wid` owns items [wid*runLen, (wid+1)*runLen) -- used for coherent primary rays
+  //    over tiny scenes, where every ray costs the same and 64-slot groups need no refilling;
+  //  dynamic mode: a persistent grid; the items are split into kFetchShards contiguous spans (one per XCD label, so that
+  //    an XCD's L2 keeps seeing the same image region) and a wave pulls chunkLen items at a time from its span's counter.
   const bool sparse = a.list != nullptr;
   const uint32_t total = sparse ? *a.listCount : a.numSlots;
+  constexpr bool dynamic = MODE != PRIMARY_GROUP;
   const uint32_t wid = xcdRemap(blockIdx.x, gridDim.x) * kWavesPerBlock + wv;
-  uint32_t runNext = min(total, wid * a.runLen);
-  const uint32_t runEnd = min(total, runNext + a.runLen);
+  uint32_t runNext = dynamic ? 0u : min(total, wid * a.runLen);
+  uint32_t runEnd = dynamic ? 0u : min(total, runNext + a.runLen);
+  const uint32_t shard = blockIdx.x % kFetchShards;
+  const uint32_t chunksPerShard = dynamic ? ((total + kFetchShards - 1) / kFetchShards + a.chunkLen - 1) / a.chunkLen : 0u;
+  bool exhausted = !dynamic; // dynamic mode: no more chunks in this wave's span
+  // pulls the next chunk of this wave's span into [runNext, runEnd)
+  auto fetchChunk = [&]() {
+    uint32_t c = 0;
+    if (lane == 0)
+      c = atomicAdd(a.fetch + shard * kFetchStride, 1u);
+    c = __builtin_amdgcn_readfirstlane(c);
+    const uint32_t base = (shard * chunksPerShard + c) * a.chunkLen;
+    if (c >= chunksPerShard || base >= total)
+      exhausted = true;
+    else
+    {
+      runNext = base;
+      runEnd = min(total, base + a.chunkLen);
+    }
+  };
 
   // wave-uniform work-list state
   uint32_t listCount = 0, listNext = 0;
@@ -234,10 +265,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
 
   for (;;)
   {
-    if (MODE == PRIMARY)
+    if (MODE == PRIMARY_GROUP)
     {
-      // ---------------- primary rays are coherent: take the run 64 slots (one 8x8 pixel block) at a time, generate the
-      // rays in registers at full occupancy, traverse until the whole group is done, store the 64 hit records together
+      // ---------------- coherent primary rays over a tiny scene: take the run 64 slots (one 8x8 pixel block) at a time,
+      // generate the rays in registers at full occupancy, traverse until the whole group is done, store the 64 hit
+      // records together
       if (__ballot(active) == 0)
       {
         if (groupValid)
@@ -268,11 +300,58 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
         continue;
       }
     }
+    else if (MODE == PRIMARY)
+    {
+      // ---------------- primary rays over a real scene: neighbouring pixels still walk very different numbers of nodes,
+      // so idle lanes are refilled with the next consecutive slots of the chunk once half the wave is idle
+      const uint64_t idleMask = __ballot(!active);
+      const uint32_t numIdle = __popcll(idleMask);
+      if (numIdle >= 32)
+      {
+        if (runNext >= runEnd && !exhausted)
+          fetchChunk();
+        if (runNext < runEnd)
+        {
+          const uint32_t r = rankIn(idleMask);
+          const uint32_t avail = runEnd - runNext;
+          if (!active && r < avail)
+          {
+            slot = runNext + r;
+            uint32_t sidx, i, w, h;
+            sampleOf(a.geom, slot, sidx, i);
+            if (pixelOf(a.geom, i, w, h))
+            {
+              const uint32_t samp = a.sampBegin + sidx;
+              rtd::primaryRay(*a.cam, a.geom.width, a.geom.height, w, h, samp, rtd::rand01(w, h, samp), o, d);
+              invD = rtd::padInvDir(d);
+              oi = o * invD;
+              best = FLT_MAX;
+              cull = FLT_MAX;
+              bestRec = RTFLAT_INVALID;
+              cur = RTFLAT_INVALID;
+              mk = 0;
+              sp = spLo = 0;
+              active = true;
+              nRays++;
+            }
+          }
+          runNext += min(numIdle, avail);
+        }
+      }
+      if (__ballot(active) == 0)
+      {
+        if (exhausted && runNext >= runEnd)
+          break;
+        continue;
+      }
+    }
     else
     {
       // ---------------- work list: scan + compact the next chunk of the run when the list has run dry
       const uint64_t idleMask = __ballot(!active);
       const uint32_t numIdle = __popcll(idleMask);
+      if (listNext >= listCount && numIdle >= kRefillThreshold && runNext >= runEnd && !exhausted)
+        fetchChunk();
       if (listNext >= listCount && runNext < runEnd && numIdle >= kRefillThreshold)
       {
         const uint32_t chunkEnd = min(runEnd, runNext + kChunk);
@@ -337,7 +416,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
       }
       if (__ballot(active) == 0)
       {
-        if (runNext >= runEnd && listNext >= listCount)
+        if (exhausted && runNext >= runEnd && listNext >= listCount)
           break;
         continue;
       }
@@ -389,11 +468,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
             else
               a.pb.mask[slot] = (uint8_t)occluded;
           }
-          else if (MODE == CLOSEST)
+          else if (MODE == CLOSEST || MODE == PRIMARY)
             a.pb.hit[slot] = make_uint2(__float_as_uint(best), bestRec);
           else if (MODE == ANYPROBE)
             a.anyOut[slot] = 0;
-          // PRIMARY: the group's hit records are stored together once every lane has finished
+          // static PRIMARY: the group's hit records are stored together once every lane has finished
           if (done)
             active = false;
           continue;
@@ -410,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
       rtd::padSlab(vec3{q0.x, q0.y, q0.z}, vec3{q0.w, q1.x, q1.y}, invD, oi, en0, ex0);
       rtd::padSlab(vec3{q1.z, q1.w, q2.x}, vec3{q2.y, q2.z, q2.w}, invD, oi, en1, ex1);
       const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-      constexpr bool kClosest = (MODE == CLOSEST || MODE == PRIMARY);
+      constexpr bool kClosest = isClosest(MODE);
       const bool h0 = (en0 <= ex0) && (!kClosest || en0 <= cull);
       const bool h1 = (en1 <= ex1) && (!kClosest || en1 <= cull);
       if (h0 && h1)
@@ -466,7 +545,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
           atomicAdd(&a.counters->nonFinite, 1ull);
         if (acc != 1)
           continue;
-        if (MODE == CLOSEST || MODE == PRIMARY)
+        if (isClosest(MODE))
         {
           bool better = t < best;
           if (!better && t == best)
@@ -488,7 +567,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
           break;
         }
       }
-      if (MODE != CLOSEST && MODE != PRIMARY && anyAccepted)
+      if (!isClosest(MODE) && anyAccepted)
       {
         // first accepted triangle ends an any-hit ray (testModel returns true, CPUScene.cpp:182)
         bool done = true;
@@ -550,19 +629,19 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
     if (nRays)
     {
       unsigned long long* dst =
-          (MODE == SHADOW) ? &a.counters->shadow : ((MODE == PRIMARY || a.depth == 0) ? &a.counters->extendPrimary : &a.counters->extendSecondary);
+          (MODE == SHADOW) ? &a.counters->shadow : ((isPrimary(MODE) || a.depth == 0) ? &a.counters->extendPrimary : &a.counters->extendSecondary);
       atomicAdd(dst, (unsigned long long)nRays);
     }
     if (COUNT && nNodes)
     {
       atomicAdd(&a.counters->nodesVisited, (unsigned long long)nNodes);
-      if (MODE == CLOSEST || MODE == PRIMARY)
+      if (isClosest(MODE))
         atomicAdd(&a.counters->nodesExtend, (unsigned long long)nNodes);
     }
     if (COUNT && nTris)
     {
       atomicAdd(&a.counters->trisTested, (unsigned long long)nTris);
-      if (MODE == CLOSEST || MODE == PRIMARY)
+      if (isClosest(MODE))
         atomicAdd(&a.counters->trisExtend, (unsigned long long)nTris);
     }
   }
@@ -977,7 +1056,8 @@ struct rthip_ctx
   hipStream_t stream = nullptr;
   hipEvent_t evA = nullptr, evB = nullptr, evK0 = nullptr, evK1 = nullptr;
   int numCUs = 256;
-  uint32_t traceBlocks = 2048;
+  uint32_t traceBlocks = 2048; // persistent grid of the dynamic mode
+  uint32_t fetchCursor = 0;    // next unused counter set of the current batch
   // scene
   bool haveScene = false;
   rtflat_info info{};
@@ -1001,7 +1081,7 @@ struct rthip_ctx
   DevBuf<float> acc, img, rowScratch;
   DevBuf<uint32_t> aovTri;
   DevBuf<uint8_t> aovShadow;
-  DevBuf<uint32_t> spill;
+  DevBuf<uint32_t> spill, fetch;
   DevBuf<uint32_t> listA, listB; // sparse-mode slot lists (even / odd depth)
   uint32_t spillCap = 1;         // per-lane spill entries the uploaded BVH can need
   uint32_t sparseCap = 0;        // capacity of listA / listB
@@ -1058,16 +1138,22 @@ struct KernelTimer
   }
 };
 
-// grid of a traversal launch over `total` work items: one run of runLen items per wave, runs sized so that the
-// chip (numCUs x 8 blocks) is covered several times over when there is enough work
-void traceGeometry(const rthip_ctx* c, uint32_t total, uint32_t& blocks, uint32_t& runLen)
+// static mode: one run of runLen items per wave, as many blocks as it takes
+void staticGeometry(uint32_t total, uint32_t& blocks, uint32_t& runLen)
 {
-  const uint32_t wavesWanted = (uint32_t)c->numCUs * 8u * kWavesPerBlock * 4u;
-  uint32_t rl = (total + wavesWanted - 1) / wavesWanted;
-  rl = ((rl + 63u) / 64u) * 64u;
-  runLen = std::max(64u, std::min(rl, kMaxRun));
+  runLen = kMaxRun;
   const uint32_t waves = (total + runLen - 1) / runLen;
   blocks = std::max(1u, (waves + kWavesPerBlock - 1) / kWavesPerBlock);
+}
+// dynamic mode: persistent grid, chunks sized so that every resident wave fetches ~8 times when there is that much work
+void dynamicGeometry(const rthip_ctx* c, uint32_t total, uint32_t& blocks, uint32_t& chunkLen)
+{
+  const uint32_t waves = c->traceBlocks * kWavesPerBlock;
+  uint32_t cl = (total + waves * 8u - 1) / (waves * 8u);
+  cl = ((cl + 63u) / 64u) * 64u;
+  chunkLen = std::max(64u, std::min(cl, 4u * kChunk)); // a fetched span is scanned kChunk items at a time
+  const uint32_t wavesNeeded = (total + chunkLen - 1) / chunkLen;
+  blocks = std::max(kFetchShards, std::min(c->traceBlocks, (wavesNeeded + kWavesPerBlock - 1) / kWavesPerBlock));
 }
 
 int ensurePathBuffers(rthip_ctx* c, size_t numSlots)
@@ -1077,8 +1163,11 @@ int ensurePathBuffers(rthip_ctx* c, size_t numSlots)
       (rc = c->hit.ensure(numSlots)) || (rc = c->live.ensure(numSlots + 64)) || (rc = c->mask.ensure(numSlots)))
     return rc;
   uint32_t blocks, runLen;
-  traceGeometry(c, (uint32_t)numSlots, blocks, runLen);
+  staticGeometry((uint32_t)numSlots, blocks, runLen);
+  blocks = std::max(blocks, c->traceBlocks);
   if ((rc = c->spill.ensure((size_t)c->spillCap * blocks * kBlock)))
+    return rc;
+  if ((rc = c->fetch.ensure((size_t)kMaxTraceLaunches * kFetchShards * kFetchStride)))
     return rc;
   c->sparseCap = (uint32_t)std::max<size_t>(4096, numSlots / 32);
   if ((rc = c->listA.ensure(c->sparseCap)) || (rc = c->listB.ensure(c->sparseCap)))
@@ -1109,10 +1198,22 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   a.tmax = tmax;
   a.anyOut = c->anyOut.p;
   uint32_t blocks;
-  traceGeometry(c, list ? bound : numSlots, blocks, a.runLen);
+  constexpr bool staticMode = MODE == PRIMARY_GROUP;
+  a.runLen = 0;
+  a.chunkLen = 0;
+  a.fetch = nullptr;
+  if (staticMode)
+    staticGeometry(numSlots, blocks, a.runLen);
+  else
+  {
+    dynamicGeometry(c, list ? bound : numSlots, blocks, a.chunkLen);
+    if (c->fetchCursor >= kMaxTraceLaunches)
+      return RTHIP_E_LIMIT;
+    a.fetch = c->fetch.p + (size_t)(c->fetchCursor++) * kFetchShards * kFetchStride;
+  }
   if ((size_t)c->spillCap * blocks * kBlock > c->spill.n)
     return RTHIP_E_LIMIT;
-  KernelTimer kt(c, (MODE == CLOSEST || MODE == PRIMARY) ? 1 : 3);
+  KernelTimer kt(c, isClosest(MODE) ? 1 : 3);
   if (c->countWork)
     hipLaunchKernelGGL((k_trace<MODE, true>), dim3(blocks), dim3(kBlock), 0, c->stream, a);
   else
@@ -1141,6 +1242,8 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count)
   const uint32_t numSlots = P * count;
   const uint32_t shadeBlocksDense = std::max(1u, std::min((numSlots + kBlock - 1) / kBlock, (uint32_t)c->numCUs * 8u));
   HIPCHK(hipMemsetAsync(c->counters.p, 0, sizeof(DeviceCounters), c->stream));
+  HIPCHK(hipMemsetAsync(c->fetch.p, 0, c->fetch.n * sizeof(uint32_t), c->stream));
+  c->fetchCursor = 0;
   if (c->aovDepths)
   {
     HIPCHK(hipMemsetAsync(c->aovTri.p, 0xff, (size_t)count * c->aovDepths * P * sizeof(uint32_t), c->stream));
@@ -1182,7 +1285,11 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count)
       return rc;
     if (!last)
     {
-      if (d == 0 && fused)
+      // coherent primary rays over a scene of a few nodes cost the same everywhere: static 64-slot groups, no atomics;
+      // otherwise traversal length varies pixel to pixel and lanes are refilled from dynamically fetched chunks
+      if (d == 0 && fused && c->info.numNodes <= 64)
+        rc = launchTrace<PRIMARY_GROUP>(c, numSlots, 0, sampBegin, tmin, tmax);
+      else if (d == 0 && fused)
         rc = launchTrace<PRIMARY>(c, numSlots, 0, sampBegin, tmin, tmax);
       else
         rc = launchTrace<CLOSEST>(c, numSlots, d, sampBegin, tmin, tmax, list, bound);
@@ -1303,7 +1410,7 @@ int rthip_create(int device, rthip_ctx** out)
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
   c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  c->traceBlocks = (uint32_t)c->numCUs * 8u; // 8 blocks x 4 waves = 32 waves per CU when registers allow
+  c->traceBlocks = (uint32_t)c->numCUs * 6u; // 6 blocks x 4 waves = 24 waves per CU: what 24 KB of LDS per block admits
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&c->evA));
   HIPCHK(hipEventCreate(&c->evB));
@@ -1322,7 +1429,7 @@ int rthip_destroy(rthip_ctx* c)
   c->modelNodes.release(), c->nodes.release(), c->tris.release(), c->lights.release(), c->tileIds.release(), c->camConsts.release();
   c->rayO.release(), c->rayD.release(), c->s0.release(), c->s1.release(), c->hit.release(), c->live.release(), c->mask.release();
   c->anyOut.release(), c->acc.release(), c->img.release(), c->rowScratch.release(), c->aovTri.release(), c->aovShadow.release();
-  c->spill.release(), c->listA.release(), c->listB.release(), c->counters.release();
+  c->spill.release(), c->fetch.release(), c->listA.release(), c->listB.release(), c->counters.release();
   (void)hipEventDestroy(c->evA), (void)hipEventDestroy(c->evB), (void)hipEventDestroy(c->evK0), (void)hipEventDestroy(c->evK1);
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1806,6 +1913,8 @@ int rthip_probe_trace(rthip_ctx* c, const float* origin3, const float* dir3, uin
   HIPCHK(hipMemcpy(o.p, origin3, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d.p, dir3, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(hipMemsetAsync(c->counters.p, 0, sizeof(DeviceCounters), c->stream));
+  HIPCHK(hipMemsetAsync(c->fetch.p, 0, c->fetch.n * sizeof(uint32_t), c->stream));
+  c->fetchCursor = 0;
   hipLaunchKernelGGL(k_probe_pack, dim3((n + 255) / 256), dim3(256), 0, c->stream, o.p, d.p, n, c->rayO.p, c->rayD.p, c->live.p);
   HIPCHK(hipGetLastError());
   if ((rc = launchTrace<CLOSEST>(c, n, 0, 0, tmin, tmax)) || (rc = launchTrace<ANYPROBE>(c, n, 0, 0, tmin, tmax)))
