@@ -71,6 +71,8 @@ typedef struct rthip_counters
   uint64_t hits[16];        /* closest hits per depth */
   uint64_t nodesVisitedExtend; /* the closest-hit share of nodesVisited / trisTested (the rest is any-hit) */
   uint64_t trisTestedExtend;
+  uint64_t waveNodeSteps;   /* work counting: node steps / leaf steps executed by whole waves; x64 = lane slots offered, */
+  uint64_t waveLeafSteps;   /* so nodesVisited / (64*waveNodeSteps) is the SIMD utilisation of the node step */
 } rthip_counters;
 
 /* creates a context on `device` (a HIP device ordinal); replaces nothing in the reference (it has no device) */

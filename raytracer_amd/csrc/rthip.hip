@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -42,6 +43,9 @@ constexpr uint32_t kWavesPerBlock = kBlock / 64;
 constexpr uint32_t kChunk = 512;       // work items a wave scans and compacts at a time
 constexpr uint32_t kStackLds = 16;     // stack entries per lane kept in LDS
 constexpr uint32_t kMaxStack = 96;     // deepest triangle BVH accepted (LDS part + spill)
+constexpr uint32_t kLeafTrigger = 4;    // lanes that must be waiting on a leaf before a wave takes a leaf step (tuned on the 1M soup)
+constexpr uint32_t kDone = 0xffffffffu; // `cur`: the ray has no node, leaf or model left (== RTFLAT_INVALID)
+constexpr uint32_t kNone = 0xfffffffeu; // `cur` / `postponed`: empty
 constexpr uint32_t kRefillThreshold = 16; // refill once this many lanes are idle (or no lane is active)
 constexpr uint32_t kMaxRun = 1024;     // most work items one wave is handed (static mode)
 constexpr uint32_t kFetchShards = 8;   // one work counter per XCD label (blockIdx % 8): 8x the atomic rate of one word, L2-local ranges
@@ -83,6 +87,7 @@ struct Lights
 struct DeviceCounters
 {
   unsigned long long extendPrimary, extendSecondary, shadow, nodesVisited, trisTested, nonFinite, nodesExtend, trisExtend;
+  unsigned long long waveNodeSteps, waveLeafSteps; // work counting: node / leaf steps executed by waves (x64 = lane slots offered)
   unsigned long long hits[16];
   unsigned long long alive[kMaxDepthSlots + 2]; // paths alive at each depth of the current batch
   uint32_t listCount[kMaxDepthSlots + 2];       // sparse mode: entries of the slot list of each depth
@@ -190,6 +195,8 @@ struct TraceArgs
   const uint32_t* listCount; // sparse: number of work items (device memory)
   uint32_t runLen;           // static mode: work items per wave (multiple of 64, <= kMaxRun)
   uint32_t chunkLen;         // dynamic mode: work items per fetch (multiple of 64)
+  uint32_t refillAt;         // idle lanes that trigger a refill from the work list
+  uint32_t leafTrigger;      // lanes waiting on a leaf that trigger a leaf step
   uint32_t* fetch;           // dynamic mode: kFetchShards counters, kFetchStride words apart, zeroed before the launch
   uint32_t depth;            // live[] value this launch serves (dense mode filter)
   uint32_t* spill;           // [spillCap][gridLanes]
@@ -256,12 +263,14 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
   vec3 o{0, 0, 0}, d{0, 0, 1}, invD{0, 0, 0}, oi{0, 0, 0};
   float best = FLT_MAX, cull = FLT_MAX;
   uint32_t bestRec = RTFLAT_INVALID;
-  uint32_t cur = RTFLAT_INVALID; // inner node index, leaf reference, or RTFLAT_INVALID = "need next model leaf"
+  uint32_t cur = kNone;          // inner node index, a second leaf waiting for the leaf step, kDone or kNone
   uint32_t mk = 0;               // model-tree cursor (pre-order index)
   uint32_t sp = 0, spLo = 0;     // stack entries [spLo, sp) are in LDS, [0, spLo) spilled
+  uint32_t postponed = 0xfffffffeu; // a leaf reference parked while the lane keeps walking inner nodes (kNone = none)
+  bool needPop = false;          // the lane needs a new `cur` from its stack / the model tree
   uint32_t lightIdx = 0;         // SHADOW: which directional light this lane is testing
   uint32_t occluded = 0;         // SHADOW: result bits
-  uint32_t nRays = 0, nNodes = 0, nTris = 0;
+  uint32_t nRays = 0, nNodes = 0, nTris = 0, nNodeSteps = 0, nLeafSteps = 0;
 
   for (;;)
   {
@@ -290,7 +299,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
           best = FLT_MAX;
           cull = FLT_MAX;
           bestRec = RTFLAT_INVALID;
-          cur = RTFLAT_INVALID;
+          cur = kNone;
+          postponed = kNone;
+          needPop = true;
           mk = 0;
           sp = spLo = 0;
           active = true;
@@ -328,7 +339,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
               best = FLT_MAX;
               cull = FLT_MAX;
               bestRec = RTFLAT_INVALID;
-              cur = RTFLAT_INVALID;
+              cur = kNone;
+              postponed = kNone;
+              needPop = true;
               mk = 0;
               sp = spLo = 0;
               active = true;
@@ -350,9 +363,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
       // ---------------- work list: scan + compact the next chunk of the run when the list has run dry
       const uint64_t idleMask = __ballot(!active);
       const uint32_t numIdle = __popcll(idleMask);
-      if (listNext >= listCount && numIdle >= kRefillThreshold && runNext >= runEnd && !exhausted)
+      if (listNext >= listCount && numIdle >= a.refillAt && runNext >= runEnd && !exhausted)
         fetchChunk();
-      if (listNext >= listCount && runNext < runEnd && numIdle >= kRefillThreshold)
+      if (listNext >= listCount && runNext < runEnd && numIdle >= a.refillAt)
       {
         const uint32_t chunkEnd = min(runEnd, runNext + kChunk);
         uint32_t n = 0;
@@ -380,7 +393,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
       }
       // ---------------- hand list entries to idle lanes (ballot + mbcnt compaction)
       const uint32_t avail = listCount - listNext;
-      if (avail > 0 && (numIdle >= kRefillThreshold || numIdle == 64))
+      if (avail > 0 && (numIdle >= a.refillAt || numIdle == 64))
       {
         const uint32_t r = rankIn(idleMask);
         const bool take = !active && r < avail;
@@ -406,7 +419,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
           best = FLT_MAX;
           cull = FLT_MAX;
           bestRec = RTFLAT_INVALID;
-          cur = RTFLAT_INVALID;
+          cur = kNone;
+          postponed = kNone;
+          needPop = true;
           mk = 0;
           sp = spLo = 0;
           active = true;
@@ -422,100 +437,23 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
       }
     }
 
-    // ---------------- inner nodes: descend until this lane holds a leaf (or its ray is finished)
-    while (active && ((int)cur >= 0 || cur == RTFLAT_INVALID))
+    const bool refillPossible = (MODE == PRIMARY_GROUP) ? false
+                                : (MODE == PRIMARY)     ? (runNext < runEnd || !exhausted)
+                                                        : (listNext < listCount || runNext < runEnd || !exhausted);
+    const uint32_t refillAt = (MODE == PRIMARY) ? 32u : a.refillAt;
+    // ---------------- traversal: a wave alternates NODE steps (every lane that holds an inner node tests its two child
+    // boxes) with LEAF steps (every lane that holds a postponed leaf runs the reference's triangle test on it).  A lane
+    // that reaches a leaf parks it in `postponed` and keeps walking inner nodes; the leaf step is taken only once
+    // kLeafTrigger lanes cannot go on without it (they met a second leaf, or have nothing else left) or no lane can do a
+    // node step.  Compared with a plain while-while loop, where every lane waits at its leaf until the slowest lane has
+    // found one, this keeps most lanes busy in both kinds of step.
+    for (;;)
     {
-      if (cur == RTFLAT_INVALID)
+      // --- resolve: lanes that need a new `cur` pop their stack, or walk on to the next model leaf when it is empty
+      while (active && needPop)
       {
-        // stack empty: next model leaf whose box chain passes the reference's test, in DFS order
-        // (CPUScene.cpp:123-137 / 107-121: both children always, box test with the caller's tmin/tmax)
-        uint32_t found = RTFLAT_INVALID;
-        while (mk < numModelNodes)
-        {
-          const rtflat_model_node* mn = modelNodes + mk;
-          if (COUNT)
-            nNodes++;
-          if (!rtd::refSlab(mn->lo, mn->hi, o, rt::rcp3(d) /* AABB.h:49 */, a.tmin, a.tmax))
-          {
-            mk += mn->subtreeSize; // skip the subtree
-            continue;
-          }
-          mk++;
-          if (mn->triCount > 0)
-          {
-            found = mn->blas;
-            break;
-          }
-        }
-        if (found == RTFLAT_INVALID)
-        {
-          // ray finished
-          bool done = true;
-          if (MODE == SHADOW)
-          {
-            // not occluded for this light; the next light restarts the walk
-            lightIdx++;
-            if (lightIdx < a.lights->numDir)
-            {
-              const rthip_dir_light& L = a.lights->dir[lightIdx];
-              d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]};
-              invD = rtd::padInvDir(d);
-              oi = o * invD;
-              mk = 0;
-              nRays++;
-              done = false;
-            }
-            else
-              a.pb.mask[slot] = (uint8_t)occluded;
-          }
-          else if (MODE == CLOSEST || MODE == PRIMARY)
-            a.pb.hit[slot] = make_uint2(__float_as_uint(best), bestRec);
-          else if (MODE == ANYPROBE)
-            a.anyOut[slot] = 0;
-          // static PRIMARY: the group's hit records are stored together once every lane has finished
-          if (done)
-            active = false;
-          continue;
-        }
-        cur = found;
-        continue;
-      }
-      // one 64-byte node: both child boxes
-      const float4* np = nodes4 + (size_t)cur * 4;
-      const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-      if (COUNT)
-        nNodes++;
-      float en0, ex0, en1, ex1;
-      rtd::padSlab(vec3{q0.x, q0.y, q0.z}, vec3{q0.w, q1.x, q1.y}, invD, oi, en0, ex0);
-      rtd::padSlab(vec3{q1.z, q1.w, q2.x}, vec3{q2.y, q2.z, q2.w}, invD, oi, en1, ex1);
-      const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-      constexpr bool kClosest = isClosest(MODE);
-      const bool h0 = (en0 <= ex0) && (!kClosest || en0 <= cull);
-      const bool h1 = (en1 <= ex1) && (!kClosest || en1 <= cull);
-      if (h0 && h1)
-      {
-        const bool swap = en1 < en0;
-        const uint32_t farRef = swap ? c0 : c1;
-        cur = swap ? c1 : c0;
-        // push
-        if (sp - spLo == kStackLds)
-        {
-          spill[(size_t)spLo * gridLanes] = stack[spLo % kStackLds][lane];
-          spLo++;
-        }
-        stack[sp % kStackLds][lane] = farRef;
-        sp++;
-      }
-      else if (h0)
-        cur = c0;
-      else if (h1)
-        cur = c1;
-      else
-      {
-        // pop
-        if (sp == 0)
-          cur = RTFLAT_INVALID;
-        else
+        uint32_t got;
+        if (sp != 0)
         {
           if (sp == spLo)
           {
@@ -523,57 +461,46 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
             stack[spLo % kStackLds][lane] = spill[(size_t)spLo * gridLanes];
           }
           sp--;
-          cur = stack[sp % kStackLds][lane];
-        }
-      }
-    }
-
-    // ---------------- leaf: the reference's triangle test on every record of the leaf
-    if (active && (int)cur < 0)
-    {
-      const uint32_t first = rtflat_leaf_first(cur), count = rtflat_leaf_count(cur);
-      bool anyAccepted = false;
-      for (uint32_t k = 0; k < count; ++k)
-      {
-        const float4* tp = tris4 + (size_t)(first + k) * 4;
-        const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
-        if (COUNT)
-          nTris++;
-        float t;
-        const int acc = rtd::triangleTest(vec3{a0.x, a0.y, a0.z}, vec3{a0.w, a1.x, a1.y}, vec3{a1.z, a1.w, a2.x}, o, d, a.tmin, a.tmax, t);
-        if (acc == 2)
-          atomicAdd(&a.counters->nonFinite, 1ull);
-        if (acc != 1)
-          continue;
-        if (isClosest(MODE))
-        {
-          bool better = t < best;
-          if (!better && t == best)
-          {
-            // tie: the triangle later in (DFS model order, index in model) wins (CPUScene.cpp:231, :136)
-            const uint32_t keyNew = a.scene.tris[first + k].orderKey, keyOld = a.scene.tris[bestRec].orderKey;
-            better = keyNew > keyOld;
-          }
-          if (better)
-          {
-            best = t;
-            bestRec = first + k;
-            cull = rt::fma(best, 1.0f + a.scene.cullRel, a.scene.cullAbs);
-          }
+          got = stack[sp % kStackLds][lane];
         }
         else
         {
-          anyAccepted = true;
-          break;
+          // stack empty: next model leaf whose box chain passes the reference's test, in DFS order
+          // (CPUScene.cpp:123-137 / 107-121: both children always, box test with the caller's tmin/tmax)
+          got = kDone;
+          while (mk < numModelNodes)
+          {
+            const rtflat_model_node* mn = modelNodes + mk;
+            if (COUNT)
+              nNodes++;
+            if (!rtd::refSlab(mn->lo, mn->hi, o, rt::rcp3(d) /* AABB.h:49 */, a.tmin, a.tmax))
+            {
+              mk += mn->subtreeSize; // skip the subtree
+              continue;
+            }
+            mk++;
+            if (mn->triCount > 0)
+            {
+              got = mn->blas;
+              break;
+            }
+          }
+        }
+        if (got != kDone && (int)got < 0 && postponed == kNone)
+          postponed = got; // a leaf: park it and keep looking for inner-node work
+        else
+        {
+          cur = got;
+          needPop = false;
         }
       }
-      if (!isClosest(MODE) && anyAccepted)
+      // --- rays that have nothing left
+      if (active && cur == kDone && postponed == kNone)
       {
-        // first accepted triangle ends an any-hit ray (testModel returns true, CPUScene.cpp:182)
         bool done = true;
         if (MODE == SHADOW)
         {
-          occluded |= 1u << lightIdx;
+          // not occluded for this light; the next light restarts the walk
           lightIdx++;
           if (lightIdx < a.lights->numDir)
           {
@@ -582,36 +509,166 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
             invD = rtd::padInvDir(d);
             oi = o * invD;
             mk = 0;
-            sp = spLo = 0;
-            cur = RTFLAT_INVALID;
+            needPop = true;
+            cur = kNone;
             nRays++;
             done = false;
           }
           else
             a.pb.mask[slot] = (uint8_t)occluded;
         }
-        else
-          a.anyOut[slot] = 1;
+        else if (MODE == CLOSEST || MODE == PRIMARY)
+          a.pb.hit[slot] = make_uint2(__float_as_uint(best), bestRec);
+        else if (MODE == ANYPROBE)
+          a.anyOut[slot] = 0;
+        // PRIMARY_GROUP: the group's hit records are stored together once every lane has finished
         if (done)
           active = false;
       }
-      else
+      const bool atNode = active && !needPop && (int)cur >= 0;
+      const bool stalled = active && !needPop && postponed != kNone && !((int)cur >= 0);
+      const uint64_t nodeMask = __ballot(atNode || (active && needPop));
+      const uint32_t numStalled = __popcll(__ballot(stalled));
+      const bool leafStep = numStalled >= a.leafTrigger || (nodeMask == 0 && numStalled > 0);
+      if (leafStep)
       {
-        // pop
-        if (sp == 0)
-          cur = RTFLAT_INVALID;
-        else
+        if (COUNT)
+          nLeafSteps++;
+        // --- LEAF step: the reference's triangle test on every record of every parked leaf
+        if (active && postponed != kNone)
         {
-          if (sp == spLo)
+          const uint32_t first = rtflat_leaf_first(postponed), count = rtflat_leaf_count(postponed);
+          postponed = kNone;
+          bool anyAccepted = false;
+          for (uint32_t k = 0; k < count; ++k)
           {
-            spLo--;
-            stack[spLo % kStackLds][lane] = spill[(size_t)spLo * gridLanes];
+            const float4* tp = tris4 + (size_t)(first + k) * 4;
+            const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
+            if (COUNT)
+              nTris++;
+            float t;
+            const int acc = rtd::triangleTest(vec3{a0.x, a0.y, a0.z}, vec3{a0.w, a1.x, a1.y}, vec3{a1.z, a1.w, a2.x}, o, d, a.tmin, a.tmax, t);
+            if (acc == 2)
+              atomicAdd(&a.counters->nonFinite, 1ull);
+            if (acc != 1)
+              continue;
+            if (isClosest(MODE))
+            {
+              bool better = t < best;
+              if (!better && t == best)
+              {
+                // tie: the triangle later in (DFS model order, index in model) wins (CPUScene.cpp:231, :136)
+                const uint32_t keyNew = a.scene.tris[first + k].orderKey, keyOld = a.scene.tris[bestRec].orderKey;
+                better = keyNew > keyOld;
+              }
+              if (better)
+              {
+                best = t;
+                bestRec = first + k;
+                cull = rt::fma(best, 1.0f + a.scene.cullRel, a.scene.cullAbs);
+              }
+            }
+            else
+            {
+              anyAccepted = true;
+              break;
+            }
           }
-          sp--;
-          cur = stack[sp % kStackLds][lane];
+          if (!isClosest(MODE) && anyAccepted)
+          {
+            // first accepted triangle ends an any-hit ray (testModel returns true, CPUScene.cpp:182)
+            if (MODE == SHADOW)
+            {
+              occluded |= 1u << lightIdx;
+              lightIdx++;
+              if (lightIdx < a.lights->numDir)
+              {
+                const rthip_dir_light& L = a.lights->dir[lightIdx];
+                d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]};
+                invD = rtd::padInvDir(d);
+                oi = o * invD;
+                mk = 0;
+                sp = spLo = 0;
+                cur = kNone;
+                needPop = true;
+                nRays++;
+              }
+              else
+              {
+                a.pb.mask[slot] = (uint8_t)occluded;
+                active = false;
+              }
+            }
+            else
+            {
+              a.anyOut[slot] = 1;
+              active = false;
+            }
+          }
+          else if (!needPop && cur != kDone && (int)cur < 0)
+          {
+            // the lane was holding a second leaf: park it now and look for more work
+            postponed = cur;
+            cur = kNone;
+            needPop = true;
+          }
         }
+        continue;
+      }
+      if (nodeMask == 0)
+        break; // nothing left to traverse in this wave: back to the work list
+      // leave for a refill as soon as enough lanes are idle and there is work to hand out
+      if (refillPossible && (uint32_t)__popcll(__ballot(!active)) >= refillAt)
+        break;
+      // --- NODE step: one 64-byte node, both child boxes
+      if (COUNT)
+        nNodeSteps++;
+      if (atNode)
+      {
+        const float4* np = nodes4 + (size_t)cur * 4;
+        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+        if (COUNT)
+          nNodes++;
+        float en0, ex0, en1, ex1;
+        rtd::padSlab(vec3{q0.x, q0.y, q0.z}, vec3{q0.w, q1.x, q1.y}, invD, oi, en0, ex0);
+        rtd::padSlab(vec3{q1.z, q1.w, q2.x}, vec3{q2.y, q2.z, q2.w}, invD, oi, en1, ex1);
+        const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+        constexpr bool kClosest = isClosest(MODE);
+        const bool h0 = (en0 <= ex0) && (!kClosest || en0 <= cull);
+        const bool h1 = (en1 <= ex1) && (!kClosest || en1 <= cull);
+        uint32_t next = kNone;
+        if (h0 && h1)
+        {
+          const bool swap = en1 < en0;
+          const uint32_t farRef = swap ? c0 : c1;
+          next = swap ? c1 : c0;
+          // push the farther child
+          if (sp - spLo == kStackLds)
+          {
+            spill[(size_t)spLo * gridLanes] = stack[spLo % kStackLds][lane];
+            spLo++;
+          }
+          stack[sp % kStackLds][lane] = farRef;
+          sp++;
+        }
+        else if (h0)
+          next = c0;
+        else if (h1)
+          next = c1;
+        if (next == kNone)
+          needPop = true;
+        else if ((int)next < 0 && postponed == kNone)
+        {
+          postponed = next; // a leaf: park it, go on with the stack
+          needPop = true;
+        }
+        else
+          cur = next; // an inner node, or a second leaf (the lane now waits for the leaf step)
+        if (needPop)
+          cur = kNone;
       }
     }
+    // the wave is out of traversal work (or wants a refill): PRIMARY_GROUP and the list modes pick up from here
   }
 
   // ---------------- tallies: one atomic per wave and counter
@@ -631,6 +688,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
       unsigned long long* dst =
           (MODE == SHADOW) ? &a.counters->shadow : ((isPrimary(MODE) || a.depth == 0) ? &a.counters->extendPrimary : &a.counters->extendSecondary);
       atomicAdd(dst, (unsigned long long)nRays);
+    }
+    if (COUNT)
+    {
+      atomicAdd(&a.counters->waveNodeSteps, (unsigned long long)nNodeSteps);
+      atomicAdd(&a.counters->waveLeafSteps, (unsigned long long)nLeafSteps);
     }
     if (COUNT && nNodes)
     {
@@ -1085,6 +1147,8 @@ struct rthip_ctx
   DevBuf<uint32_t> listA, listB; // sparse-mode slot lists (even / odd depth)
   uint32_t spillCap = 1;         // per-lane spill entries the uploaded BVH can need
   uint32_t sparseCap = 0;        // capacity of listA / listB
+  uint32_t tuneBlocks = 6;
+  uint32_t tuneRefill = kRefillThreshold, tuneLeaf = kLeafTrigger;
   bool fusedPrimary = true;      // generate rays inside the depth-0 traversal kernel instead of storing them
   DevBuf<DeviceCounters> counters;
   uint32_t lastBatchBegin = 0, lastBatchCount = 0, lastSamp = 0;
@@ -1197,6 +1261,8 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   a.tmin = tmin;
   a.tmax = tmax;
   a.anyOut = c->anyOut.p;
+  a.refillAt = c->tuneRefill;
+  a.leafTrigger = c->tuneLeaf;
   uint32_t blocks;
   constexpr bool staticMode = MODE == PRIMARY_GROUP;
   a.runLen = 0;
@@ -1231,6 +1297,8 @@ void addCounters(rthip_counters& dst, const DeviceCounters& s)
   dst.nonFiniteAccepts += s.nonFinite;
   dst.nodesVisitedExtend += s.nodesExtend;
   dst.trisTestedExtend += s.trisExtend;
+  dst.waveNodeSteps += s.waveNodeSteps;
+  dst.waveLeafSteps += s.waveLeafSteps;
   for (int i = 0; i < 16; ++i)
     dst.hits[i] += s.hits[i];
 }
@@ -1410,7 +1478,16 @@ int rthip_create(int device, rthip_ctx** out)
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
   c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  c->traceBlocks = (uint32_t)c->numCUs * 6u; // 6 blocks x 4 waves = 24 waves per CU: what 24 KB of LDS per block admits
+  if (const char* t = getenv("RTHIP_TUNE")) // "refill,leaf[,blocksPerCU]" -- tuning experiments only
+  {
+    unsigned r = 0, l = 0, b = 0;
+    const int n = sscanf(t, "%u,%u,%u", &r, &l, &b);
+    if (n >= 2 && r >= 1 && r <= 64 && l >= 1 && l <= 64)
+      c->tuneRefill = r, c->tuneLeaf = l;
+    if (n >= 3 && b >= 1 && b <= 8)
+      c->tuneBlocks = b;
+  }
+  c->traceBlocks = (uint32_t)c->numCUs * c->tuneBlocks; // 6 blocks x 4 waves = 24 waves per CU: what 24 KB of LDS per block admits
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&c->evA));
   HIPCHK(hipEventCreate(&c->evB));
