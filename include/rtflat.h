@@ -17,11 +17,12 @@
  *      (built by the same pairing loop, src/cpu/CPUScene.cpp:67-105).  Its
  *      boxes are tested with the reference's exact AABB::intersects arithmetic
  *      (src/scene/AABB.h:47-60) and both children are always visited.
- *   2. rtflat_node[]        NEW: a triangle-level BVH2 below each model leaf
- *      (the reference scans every triangle of a model linearly).  Each node
- *      stores the boxes of BOTH children, padded outward, so one 64-B fetch
- *      decides both.  These boxes only ever cull conservatively: they never
- *      change which triangle the reference's arg-min would pick.
+ *   2. rtflat_node[]        NEW: a triangle-level 4-wide BVH below each model
+ *      leaf (the reference scans every triangle of a model linearly).  Each
+ *      node stores the boxes of its FOUR children, padded outward and quantised
+ *      to 8 bits, so one 64-B fetch decides four.  These boxes only ever cull
+ *      conservatively: they never change which triangle the reference's
+ *      arg-min would pick.
  *   3. rtflat_tri[]         self-contained triangle records ("Woop-style"
  *      layout: everything a ray/triangle test needs in one aligned record), in
  *      BVH leaf order.  The record holds exactly the operands the reference's
@@ -59,12 +60,20 @@ RTFLAT_FN int rtflat_is_leaf(uint32_t ref) { return (ref & RTFLAT_LEAF_BIT) != 0
 RTFLAT_FN uint32_t rtflat_leaf_first(uint32_t ref) { return (ref & 0x7fffffffu) >> 3; }
 RTFLAT_FN uint32_t rtflat_leaf_count(uint32_t ref) { return (ref & 7u) + 1u; }
 
-/* triangle-level BVH2 node: boxes of both children (padded), 64 B */
+/* triangle-level BVH node, 64 B: FOUR children whose (padded) boxes are quantised to 8 bits per coordinate relative to
+ * the node's own box.  One 64-byte fetch decides four children, so a ray makes about half the dependent fetches -- and
+ * moves half the bytes -- of a two-wide tree with full-precision boxes.  Quantisation rounds outward (lo down, hi up), so
+ * like the padding it can only make a box larger: these boxes never decide a hit, they only cull.
+ *   box of child k on axis a:  lo = origin[a] + qlo[a][k] * 2^(exp[a]-127),  hi = origin[a] + qhi[a][k] * 2^(exp[a]-127)
+ * An unused slot has child == RTFLAT_INVALID and an inverted box (qlo 255, qhi 0), which no ray hits. */
 typedef struct rtflat_node
 {
-  float lo0[3], hi0[3]; /* child 0 box */
-  float lo1[3], hi1[3]; /* child 1 box */
-  uint32_t child0, child1;
+  float origin[3];    /* lower corner of the node's box */
+  uint8_t exp[3];     /* biased exponent of the power-of-two grid step per axis (1..254) */
+  uint8_t numChildren;
+  uint32_t child[4];  /* child references (see above), RTFLAT_INVALID when unused */
+  uint8_t qlo[3][4];  /* [axis][child] */
+  uint8_t qhi[3][4];
   uint32_t pad[2];
 } rtflat_node;
 
@@ -103,7 +112,7 @@ typedef struct rtflat_info
   float originBound; /* ray origins (camera) must stay within this distance of the scene box centre */
   float cullRel;     /* closest-hit culling slack: a node is skipped only if entry > best*(1+cullRel)+cullAbs */
   float cullAbs;
-  uint32_t maxDepthBlas; /* deepest BLAS path (stack bound) */
+  uint32_t maxDepthBlas; /* deepest chain of 4-wide nodes; a traversal stack holds at most 3 entries per level */
   uint32_t numDegenerate; /* triangles whose cross(e0,e1) is exactly zero (outside the parity domain) */
   uint32_t pad[2];
 } rtflat_info;

@@ -348,9 +348,9 @@ struct orc_scene
   // The same traversal rule the HIP extend/shadow kernels implement (DESIGN.md "Traversal rule"):
   //  * model nodes: the reference's exact slab test, both children always visited, passing leaves
   //    are traversed in DFS (left to right) order;
-  //  * BVH nodes: conservative slab test on the padded child boxes with explicit fmaf, entry clamped
-  //    to 0; closest-hit additionally skips a child whose entry exceeds best*(1+cullRel)+cullAbs;
-  //    nearer child first (ties: child 0 first);
+  //  * BVH nodes (4-wide, boxes quantised outward to 8 bits): conservative slab test with explicit fmaf, entry
+  //    clamped to 0; closest-hit additionally skips a child whose entry exceeds best*(1+cullRel)+cullAbs;
+  //    children visited nearest first;
   //  * triangles: the reference's Moeller-Trumbore on the record's operands; winner = smallest t,
   //    ties -> larger orderKey (== "later triangle / right subtree wins").
   struct FlatRay
@@ -389,13 +389,68 @@ struct orc_scene
     const V3 r = 1.0f / d;
     return V3{fminf(fmaxf(r.x, -1e18f), 1e18f), fminf(fmaxf(r.y, -1e18f), 1e18f), fminf(fmaxf(r.z, -1e18f), 1e18f)};
   }
-  static inline void flatSlab(const float* lo, const float* hi, const V3& invD, const V3& oi, float& entry, float& exit)
+  // One 4-wide quantised node (include/rtflat.h): tests the four child boxes with the arithmetic of the kernels
+  // (slab distance = q * (step*invD) + (origin*invD - o*invD), explicit fmaf, entry clamped to 0) and returns the children
+  // that were hit sorted by entry distance with the kernels' 5-exchange network; key 0xffffffff marks a miss.
+  static inline void wideStep(const rtflat_node& nd, const V3& invD, const V3& oi, bool useCull, float cull, uint32_t key[4], uint32_t ref[4])
   {
-    const float ax = __builtin_fmaf(lo[0], invD.x, -oi.x), bx = __builtin_fmaf(hi[0], invD.x, -oi.x);
-    const float ay = __builtin_fmaf(lo[1], invD.y, -oi.y), by = __builtin_fmaf(hi[1], invD.y, -oi.y);
-    const float az = __builtin_fmaf(lo[2], invD.z, -oi.z), bz = __builtin_fmaf(hi[2], invD.z, -oi.z);
-    entry = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    exit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float s[3] = {stepOf(nd.exp[0]), stepOf(nd.exp[1]), stepOf(nd.exp[2])};
+    const float inv[3] = {invD.x, invD.y, invD.z}, o3[3] = {oi.x, oi.y, oi.z};
+    float a[3], b[3];
+    for (int ax = 0; ax < 3; ++ax)
+    {
+      a[ax] = s[ax] * inv[ax];
+      b[ax] = __builtin_fmaf(nd.origin[ax], inv[ax], -o3[ax]);
+    }
+    for (int k = 0; k < 4; ++k)
+    {
+      // the ray enters a slab through the low plane when it travels in +axis, through the high one otherwise; an
+      // unused slot (qlo 255, qhi 0) therefore has entry > exit for every ray
+      float nr[3], fr[3];
+      for (int ax = 0; ax < 3; ++ax)
+      {
+        const bool neg = inv[ax] < 0.0f;
+        nr[ax] = __builtin_fmaf((float)(neg ? nd.qhi[ax][k] : nd.qlo[ax][k]), a[ax], b[ax]);
+        fr[ax] = __builtin_fmaf((float)(neg ? nd.qlo[ax][k] : nd.qhi[ax][k]), a[ax], b[ax]);
+      }
+      const float entry = fmaxf(fmaxf(nr[0], nr[1]), fmaxf(nr[2], 0.0f));
+      const float exit = fminf(fminf(fr[0], fr[1]), fr[2]);
+      const bool hit = entry <= exit && (!useCull || entry <= cull);
+      uint32_t bits;
+      std::memcpy(&bits, &entry, 4);
+      key[k] = hit ? bits : 0xffffffffu;
+      ref[k] = nd.child[k];
+    }
+    auto order = [&](int i, int j) {
+      if (key[j] < key[i])
+      {
+        std::swap(key[i], key[j]);
+        std::swap(ref[i], ref[j]);
+      }
+    };
+    order(0, 1), order(2, 3), order(0, 2), order(1, 3), order(1, 2);
+  }
+  static inline float stepOf(uint8_t biasedExponent)
+  {
+    const uint32_t bits = (uint32_t)biasedExponent << 23;
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+  }
+  // shared by closest / any hit: descends from `cur`; returns the next thing to visit (leaf or node) or RTFLAT_INVALID
+  // when the stack has run empty.  Far children are pushed farthest first.
+  inline uint32_t wideDescend(uint32_t cur, const V3& invD, const V3& oi, bool useCull, float cull, uint32_t* stack, int& sp, Counters& cnt) const
+  {
+    const rtflat_node& nd = fNodes[cur];
+    cnt.nodesVisited++;
+    uint32_t key[4], ref[4];
+    wideStep(nd, invD, oi, useCull, cull, key, ref);
+    for (int k = 3; k >= 1; --k)
+      if (key[k] != 0xffffffffu)
+        stack[sp++] = ref[k];
+    if (key[0] != 0xffffffffu)
+      return ref[0];
+    return sp == 0 ? RTFLAT_INVALID : stack[--sp];
   }
   // collects the BLAS roots of the model leaves the reference would scan, in DFS order
   void flatModelLeaves(uint32_t nodeIdx, const RayO& ray, float tmin, float tmax, uint32_t* out, uint32_t& n, Counters& cnt) const
@@ -424,7 +479,7 @@ struct orc_scene
     const V3 oi = ray.origin * invD;
     float best = FLT_MAX, cull = FLT_MAX;
     uint32_t bestKey = 0, bestRec = RTFLAT_INVALID;
-    uint32_t stack[128];
+    uint32_t stack[512];
     for (uint32_t r = 0; r < nRoots; ++r)
     {
       int sp = 0;
@@ -453,29 +508,9 @@ struct orc_scene
           cur = stack[--sp];
           continue;
         }
-        const rtflat_node& nd = fNodes[cur];
-        cnt.nodesVisited++;
-        float en0, ex0, en1, ex1;
-        flatSlab(nd.lo0, nd.hi0, invD, oi, en0, ex0);
-        flatSlab(nd.lo1, nd.hi1, invD, oi, en1, ex1);
-        const bool h0 = en0 <= ex0 && en0 <= cull;
-        const bool h1 = en1 <= ex1 && en1 <= cull;
-        if (h0 && h1)
-        {
-          const bool swap = en1 < en0;
-          stack[sp++] = swap ? nd.child0 : nd.child1;
-          cur = swap ? nd.child1 : nd.child0;
-        }
-        else if (h0)
-          cur = nd.child0;
-        else if (h1)
-          cur = nd.child1;
-        else
-        {
-          if (sp == 0)
-            break;
-          cur = stack[--sp];
-        }
+        cur = wideDescend(cur, invD, oi, true, cull, stack, sp, cnt);
+        if (cur == RTFLAT_INVALID)
+          break;
       }
     }
     tBest = best;
@@ -487,7 +522,7 @@ struct orc_scene
     flatModelLeaves(fInfo.rootModelNode, ray, tmin, tmax, roots, nRoots, cnt);
     const V3 invD = flatInvDir(ray.direction);
     const V3 oi = ray.origin * invD;
-    uint32_t stack[128];
+    uint32_t stack[512];
     for (uint32_t r = 0; r < nRoots; ++r)
     {
       int sp = 0;
@@ -508,28 +543,9 @@ struct orc_scene
           cur = stack[--sp];
           continue;
         }
-        const rtflat_node& nd = fNodes[cur];
-        cnt.nodesVisited++;
-        float en0, ex0, en1, ex1;
-        flatSlab(nd.lo0, nd.hi0, invD, oi, en0, ex0);
-        flatSlab(nd.lo1, nd.hi1, invD, oi, en1, ex1);
-        const bool h0 = en0 <= ex0, h1 = en1 <= ex1;
-        if (h0 && h1)
-        {
-          const bool swap = en1 < en0;
-          stack[sp++] = swap ? nd.child0 : nd.child1;
-          cur = swap ? nd.child1 : nd.child0;
-        }
-        else if (h0)
-          cur = nd.child0;
-        else if (h1)
-          cur = nd.child1;
-        else
-        {
-          if (sp == 0)
-            break;
-          cur = stack[--sp];
-        }
+        cur = wideDescend(cur, invD, oi, false, 0.0f, stack, sp, cnt);
+        if (cur == RTFLAT_INVALID)
+          break;
       }
     }
     return false;

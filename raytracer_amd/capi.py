@@ -47,8 +47,8 @@ class FlatInfo(C.Structure):  # rtflat_info
 
 
 # numpy views of the 64-byte records of include/rtflat.h
-NODE_DTYPE = np.dtype([("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3), ("child0", "<u4"), ("child1", "<u4"),
-                       ("pad", "<u4", 2)])
+NODE_DTYPE = np.dtype([("origin", "<f4", 3), ("exp", "u1", 3), ("numChildren", "u1"), ("child", "<u4", 4), ("qlo", "u1", (3, 4)),
+                       ("qhi", "u1", (3, 4)), ("pad", "<u4", 2)])
 MODEL_NODE_DTYPE = np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("left", "<u4"), ("right", "<u4"), ("blas", "<u4"), ("triCount", "<u4"),
                              ("indicesOffset", "<u4"), ("orderBase", "<u4"), ("modelIndex", "<u4"), ("subtreeSize", "<u4"),
                              ("pad", "<u4", 2)])

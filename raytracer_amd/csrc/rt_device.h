@@ -199,13 +199,47 @@ RTD vec3 padInvDir(vec3 d)
   return vec3{fminf(fmaxf(r.x, -1e18f), 1e18f), fminf(fmaxf(r.y, -1e18f), 1e18f), fminf(fmaxf(r.z, -1e18f), 1e18f)};
 }
 
-// ---- conservative slab test for the padded triangle-BVH boxes (no counterpart in the reference)
-RTD void padSlab(vec3 lo, vec3 hi, vec3 invD, vec3 oi, float& entry, float& exit)
+// ---- conservative slab tests for the 4-wide quantised triangle-BVH nodes (no counterpart in the reference).
+// child box on axis a: origin[a] + q * step[a]; its slab distances are q * (step*invD) + (origin*invD - o*invD), so the
+// per-node part is 3 multiplies + 3 FMAs and every plane of every child costs one FMA.
+struct WideNode
 {
-  const float ax = rt::fma(lo.x, invD.x, -oi.x), bx = rt::fma(hi.x, invD.x, -oi.x);
-  const float ay = rt::fma(lo.y, invD.y, -oi.y), by = rt::fma(hi.y, invD.y, -oi.y);
-  const float az = rt::fma(lo.z, invD.z, -oi.z), bz = rt::fma(hi.z, invD.z, -oi.z);
-  entry = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-  exit = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+  float ax, ay, az, bx, by, bz; // per-axis slope and offset of the slab distance as a function of the grid coordinate
+  uint32_t nx, ny, nz, fx, fy, fz; // 4 children x 8 bits each: the grid planes the ray enters / leaves through
+};
+// The plane a ray enters a slab through is the low one when it travels in +axis and the high one otherwise, so the
+// near/far choice is made once per node (six selects) instead of per child with min/max.  An unused slot (qlo 255,
+// qhi 0) then has entry > exit for every ray.
+RTD WideNode wideNodeSetup(float4 w0, float4 w2, float4 w3, vec3 invD, vec3 oi)
+{
+  WideNode n;
+  const uint32_t e = __float_as_uint(w0.w);
+  const float sx = __uint_as_float((e & 0xffu) << 23), sy = __uint_as_float(((e >> 8) & 0xffu) << 23), sz = __uint_as_float(((e >> 16) & 0xffu) << 23);
+  n.ax = sx * invD.x, n.ay = sy * invD.y, n.az = sz * invD.z;
+  n.bx = rt::fma(w0.x, invD.x, -oi.x), n.by = rt::fma(w0.y, invD.y, -oi.y), n.bz = rt::fma(w0.z, invD.z, -oi.z);
+  const uint32_t qlx = __float_as_uint(w2.x), qly = __float_as_uint(w2.y), qlz = __float_as_uint(w2.z), qhx = __float_as_uint(w2.w);
+  const uint32_t qhy = __float_as_uint(w3.x), qhz = __float_as_uint(w3.y);
+  const bool bx = invD.x < 0.0f, by = invD.y < 0.0f, bz = invD.z < 0.0f;
+  n.nx = bx ? qhx : qlx, n.fx = bx ? qlx : qhx;
+  n.ny = by ? qhy : qly, n.fy = by ? qly : qhy;
+  n.nz = bz ? qhz : qlz, n.fz = bz ? qlz : qhz;
+  return n;
+}
+template <int K>
+RTD void wideSlab(const WideNode& n, float& entry, float& exit)
+{
+  const float nx = rt::fma((float)((n.nx >> (8 * K)) & 0xffu), n.ax, n.bx), fx = rt::fma((float)((n.fx >> (8 * K)) & 0xffu), n.ax, n.bx);
+  const float ny = rt::fma((float)((n.ny >> (8 * K)) & 0xffu), n.ay, n.by), fy = rt::fma((float)((n.fy >> (8 * K)) & 0xffu), n.ay, n.by);
+  const float nz = rt::fma((float)((n.nz >> (8 * K)) & 0xffu), n.az, n.bz), fz = rt::fma((float)((n.fz >> (8 * K)) & 0xffu), n.az, n.bz);
+  entry = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+  exit = fminf(fminf(fx, fy), fz);
+}
+// compare-exchange on (key, ref): afterwards ka <= kb.  Keys are the bit patterns of non-negative distances
+// (0xffffffff = missed), so unsigned order == distance order.
+RTD void orderPair(uint32_t& ka, uint32_t& ra, uint32_t& kb, uint32_t& rb)
+{
+  const bool sw = kb < ka;
+  const uint32_t k0 = sw ? kb : ka, k1 = sw ? ka : kb, r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+  ka = k0, kb = k1, ra = r0, rb = r1;
 }
 } // namespace rtd

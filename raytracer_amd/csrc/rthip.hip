@@ -620,50 +620,58 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
       // leave for a refill as soon as enough lanes are idle and there is work to hand out
       if (refillPossible && (uint32_t)__popcll(__ballot(!active)) >= refillAt)
         break;
-      // --- NODE step: one 64-byte node, both child boxes
+      // --- NODE step: one 64-byte node = four quantised child boxes
       if (COUNT)
         nNodeSteps++;
       if (atNode)
       {
         const float4* np = nodes4 + (size_t)cur * 4;
-        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+        const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
         if (COUNT)
           nNodes++;
-        float en0, ex0, en1, ex1;
-        rtd::padSlab(vec3{q0.x, q0.y, q0.z}, vec3{q0.w, q1.x, q1.y}, invD, oi, en0, ex0);
-        rtd::padSlab(vec3{q1.z, q1.w, q2.x}, vec3{q2.y, q2.z, q2.w}, invD, oi, en1, ex1);
-        const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+        const rtd::WideNode wn = rtd::wideNodeSetup(w0, w2, w3, invD, oi);
+        float en0, ex0, en1, ex1, en2, ex2, en3, ex3;
+        rtd::wideSlab<0>(wn, en0, ex0);
+        rtd::wideSlab<1>(wn, en1, ex1);
+        rtd::wideSlab<2>(wn, en2, ex2);
+        rtd::wideSlab<3>(wn, en3, ex3);
         constexpr bool kClosest = isClosest(MODE);
-        const bool h0 = (en0 <= ex0) && (!kClosest || en0 <= cull);
-        const bool h1 = (en1 <= ex1) && (!kClosest || en1 <= cull);
-        uint32_t next = kNone;
-        if (h0 && h1)
-        {
-          const bool swap = en1 < en0;
-          const uint32_t farRef = swap ? c0 : c1;
-          next = swap ? c1 : c0;
-          // push the farther child
+        // sort the (at most four) children that were hit by entry distance; unused slots have inverted boxes
+        uint32_t k0 = ((en0 <= ex0) && (!kClosest || en0 <= cull)) ? __float_as_uint(en0) : 0xffffffffu;
+        uint32_t k1 = ((en1 <= ex1) && (!kClosest || en1 <= cull)) ? __float_as_uint(en1) : 0xffffffffu;
+        uint32_t k2 = ((en2 <= ex2) && (!kClosest || en2 <= cull)) ? __float_as_uint(en2) : 0xffffffffu;
+        uint32_t k3 = ((en3 <= ex3) && (!kClosest || en3 <= cull)) ? __float_as_uint(en3) : 0xffffffffu;
+        uint32_t r0 = __float_as_uint(w1.x), r1 = __float_as_uint(w1.y), r2 = __float_as_uint(w1.z), r3 = __float_as_uint(w1.w);
+        rtd::orderPair(k0, r0, k1, r1);
+        rtd::orderPair(k2, r2, k3, r3);
+        rtd::orderPair(k0, r0, k2, r2);
+        rtd::orderPair(k1, r1, k3, r3);
+        rtd::orderPair(k1, r1, k2, r2);
+        // push the farther ones, farthest first, so that the nearest of them is popped first
+        auto push = [&](uint32_t ref) {
           if (sp - spLo == kStackLds)
           {
             spill[(size_t)spLo * gridLanes] = stack[spLo % kStackLds][lane];
             spLo++;
           }
-          stack[sp % kStackLds][lane] = farRef;
+          stack[sp % kStackLds][lane] = ref;
           sp++;
-        }
-        else if (h0)
-          next = c0;
-        else if (h1)
-          next = c1;
-        if (next == kNone)
+        };
+        if (k3 != 0xffffffffu)
+          push(r3);
+        if (k2 != 0xffffffffu)
+          push(r2);
+        if (k1 != 0xffffffffu)
+          push(r1);
+        if (k0 == 0xffffffffu)
           needPop = true;
-        else if ((int)next < 0 && postponed == kNone)
+        else if ((int)r0 < 0 && postponed == kNone)
         {
-          postponed = next; // a leaf: park it, go on with the stack
+          postponed = r0; // a leaf: park it, go on with the stack
           needPop = true;
         }
         else
-          cur = next; // an inner node, or a second leaf (the lane now waits for the leaf step)
+          cur = r0; // an inner node, or a second leaf (the lane now waits for the leaf step)
         if (needPop)
           cur = kNone;
       }
@@ -1523,8 +1531,8 @@ int rthip_upload_scene(rthip_ctx* c, const rtflat_info* info, const rtflat_model
     return RTHIP_E_ARG;
   if (numDirLights > kMaxLights || numPointLights > kMaxLights || info->numTris >= (1u << 28) - 1u)
     return RTHIP_E_LIMIT;
-  // the per-lane stack must hold the deepest root-to-leaf chain of far children
-  if (info->maxDepthBlas + 2 > kMaxStack)
+  // the per-lane stack must hold up to three postponed children per level of the deepest chain
+  if (3 * info->maxDepthBlas + 2 > kMaxStack)
     return RTHIP_E_LIMIT;
   // host-side shape checks before any kernel dereferences these indices
   for (uint32_t k = 0; k < info->numModelNodes; ++k)
@@ -1540,13 +1548,13 @@ int rthip_upload_scene(rthip_ctx* c, const rtflat_info* info, const rtflat_model
     }
   }
   for (uint32_t k = 0; k < info->numNodes; ++k)
-  {
-    if (info->numNodes == 1 && nodes[k].child0 == 0 && nodes[k].child1 == 0)
-      break; // placeholder node of a scene whose models are all single leaves
-    for (uint32_t ref : {nodes[k].child0, nodes[k].child1})
+    for (uint32_t ref : nodes[k].child)
+    {
+      if (ref == RTFLAT_INVALID)
+        continue; // unused slot (its box is inverted)
       if (rtflat_is_leaf(ref) ? (rtflat_leaf_first(ref) + rtflat_leaf_count(ref) > info->numTris) : (ref >= info->numNodes || ref <= k))
         return RTHIP_E_ARG; // children follow their parent (pre-order): no cycles
-  }
+    }
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
   int rc;
@@ -1566,7 +1574,7 @@ int rthip_upload_scene(rthip_ctx* c, const rtflat_info* info, const rtflat_model
     L.point[i] = pointLights[i];
   HIPCHK(hipMemcpy(c->lights.p, &L, sizeof(L), hipMemcpyHostToDevice));
   c->info = *info;
-  c->spillCap = info->maxDepthBlas + 2 > kStackLds ? info->maxDepthBlas + 2 - kStackLds : 1u;
+  c->spillCap = 3 * info->maxDepthBlas + 2 > kStackLds ? 3 * info->maxDepthBlas + 2 - kStackLds : 1u;
   c->spill.release(); // sized per scene in ensurePathBuffers
   c->haveScene = true;
   c->haveFrame = false;

@@ -72,6 +72,14 @@ struct PrimBox
   float lo[3], hi[3];
 };
 
+// the binary tree the SAH builder produces; it is collapsed into 4-wide quantised nodes afterwards
+struct BinaryNode
+{
+  float lo0[3], hi0[3]; // child 0 box
+  float lo1[3], hi1[3]; // child 1 box
+  uint32_t child0, child1;
+};
+
 inline void growBox(float* lo, float* hi, const float* blo, const float* bhi)
 {
   for (int a = 0; a < 3; ++a)
@@ -90,23 +98,14 @@ struct BlasBuilder
 {
   const PrimBox* prims;   // indexed by model-local triangle index
   uint32_t* order;        // permutation of the model's triangles, partitioned in place
-  rtflat_node* scratch;   // node pool shared by all models
+  BinaryNode* scratch;    // node pool shared by all models
   std::atomic<uint32_t>* nextNode;
   uint32_t recordBase;    // first rtflat_tri record of this model
   uint32_t maxLeaf, bins;
   std::atomic<int> spareThreads{0};
-  std::atomic<uint32_t> deepest{0};
 
   static constexpr uint32_t kMaxBins = 32;
   static constexpr uint32_t kSpawnThreshold = 1u << 16;
-
-  void noteDepth(uint32_t d)
-  {
-    uint32_t cur = deepest.load(std::memory_order_relaxed);
-    while (d > cur && !deepest.compare_exchange_weak(cur, d, std::memory_order_relaxed))
-    {
-    }
-  }
 
   // builds the subtree over order[b, e); returns its child reference and writes its bounds
   uint32_t build(uint32_t b, uint32_t e, float* outLo, float* outHi, uint32_t depth)
@@ -221,8 +220,7 @@ struct BlasBuilder
     }
 
     const uint32_t me = nextNode->fetch_add(1, std::memory_order_relaxed);
-    rtflat_node node{};
-    noteDepth(depth + 1);
+    BinaryNode node{};
     uint32_t c0ref, c1ref;
     bool spawned = false;
     if (n >= kSpawnThreshold && spareThreads.fetch_sub(1, std::memory_order_relaxed) > 0)
@@ -248,37 +246,121 @@ struct BlasBuilder
   }
 };
 
-// renumber the scratch nodes reachable from `root` in depth-first pre-order (child 0 right after its parent)
-uint32_t emitPreOrder(const rtflat_node* scratch, uint32_t root, std::vector<rtflat_node>& out)
+// Collapses the binary tree under `root` into 4-wide nodes (the child with the largest box is opened until a node has
+// four children or only leaves), quantises the child boxes outward onto the node's 8-bit grid and appends the nodes to
+// `out` in depth-first pre-order (first inner child right after its parent).  Returns the reference of the new root and
+// the deepest chain of 4-wide nodes through `deepest`.
+struct Candidate
+{
+  uint32_t ref;
+  float lo[3], hi[3];
+};
+
+void quantiseNode(const Candidate* c, uint32_t n, rtflat_node& node)
+{
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (uint32_t k = 0; k < n; ++k)
+    growBox(lo, hi, c[k].lo, c[k].hi);
+  node = rtflat_node{};
+  node.numChildren = (uint8_t)n;
+  if (n == 0)
+    lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.0f;
+  for (int a = 0; a < 3; ++a)
+  {
+    node.origin[a] = lo[a];
+    const double ext = (double)hi[a] - (double)lo[a];
+    int e = -100;
+    if (ext > 0.0)
+    {
+      e = (int)std::ceil(std::log2(ext / 255.0));
+      while (std::ceil(ext / std::ldexp(1.0, e)) > 255.0)
+        ++e;
+    }
+    e = std::max(-126, std::min(e, 126));
+    node.exp[a] = (uint8_t)(e + 127);
+    const double step = std::ldexp(1.0, e);
+    for (uint32_t k = 0; k < 4; ++k)
+    {
+      if (k >= n)
+      {
+        node.qlo[a][k] = 255; // inverted box: never hit
+        node.qhi[a][k] = 0;
+        continue;
+      }
+      // outward: the grid value at or below lo, at or above hi (all products are exact in double)
+      double ql = std::floor(((double)c[k].lo[a] - (double)lo[a]) / step);
+      double qh = std::ceil(((double)c[k].hi[a] - (double)lo[a]) / step);
+      ql = std::max(0.0, std::min(ql, 255.0));
+      qh = std::max(0.0, std::min(qh, 255.0));
+      while (ql > 0.0 && (double)lo[a] + ql * step > (double)c[k].lo[a])
+        ql -= 1.0;
+      while (qh < 255.0 && (double)lo[a] + qh * step < (double)c[k].hi[a])
+        qh += 1.0;
+      node.qlo[a][k] = (uint8_t)ql;
+      node.qhi[a][k] = (uint8_t)qh;
+    }
+  }
+  for (uint32_t k = 0; k < 4; ++k)
+    node.child[k] = k < n ? c[k].ref : RTFLAT_INVALID;
+}
+
+uint32_t emitWide(const BinaryNode* scratch, uint32_t root, std::vector<rtflat_node>& out, uint32_t& deepest)
 {
   if (rtflat_is_leaf(root))
     return root;
   struct Pending
   {
-    uint32_t scratchIndex;
+    uint32_t binaryIndex;
     uint32_t parentOut; // where to patch the reference (RTFLAT_INVALID for the root)
-    int slot;
+    uint32_t slot, depth;
   };
   std::vector<Pending> stack;
-  stack.push_back({root, RTFLAT_INVALID, 0});
+  stack.push_back({root, RTFLAT_INVALID, 0, 1});
   uint32_t rootOut = RTFLAT_INVALID;
+  auto halfAreaOf = [](const Candidate& c) { return halfArea(c.lo, c.hi); };
   while (!stack.empty())
   {
     const Pending p = stack.back();
     stack.pop_back();
+    deepest = std::max(deepest, p.depth);
+    Candidate cand[4];
+    uint32_t n = 2;
+    const BinaryNode& b = scratch[p.binaryIndex];
+    cand[0].ref = b.child0, cand[1].ref = b.child1;
+    std::memcpy(cand[0].lo, b.lo0, 12), std::memcpy(cand[0].hi, b.hi0, 12);
+    std::memcpy(cand[1].lo, b.lo1, 12), std::memcpy(cand[1].hi, b.hi1, 12);
+    while (n < 4)
+    {
+      int pick = -1;
+      float bestArea = -1.0f;
+      for (uint32_t k = 0; k < n; ++k)
+        if (!rtflat_is_leaf(cand[k].ref) && halfAreaOf(cand[k]) > bestArea)
+        {
+          bestArea = halfAreaOf(cand[k]);
+          pick = (int)k;
+        }
+      if (pick < 0)
+        break;
+      const BinaryNode& open = scratch[cand[pick].ref];
+      for (uint32_t k = n; k > (uint32_t)pick + 1; --k) // keep the children of the opened node next to each other
+        cand[k] = cand[k - 1];
+      cand[pick].ref = open.child0;
+      std::memcpy(cand[pick].lo, open.lo0, 12), std::memcpy(cand[pick].hi, open.hi0, 12);
+      cand[pick + 1].ref = open.child1;
+      std::memcpy(cand[pick + 1].lo, open.lo1, 12), std::memcpy(cand[pick + 1].hi, open.hi1, 12);
+      ++n;
+    }
     const uint32_t mine = (uint32_t)out.size();
-    out.push_back(scratch[p.scratchIndex]);
+    rtflat_node node;
+    quantiseNode(cand, n, node);
+    out.push_back(node);
     if (p.parentOut == RTFLAT_INVALID)
       rootOut = mine;
-    else if (p.slot == 0)
-      out[p.parentOut].child0 = mine;
     else
-      out[p.parentOut].child1 = mine;
-    const rtflat_node& n = scratch[p.scratchIndex];
-    if (!rtflat_is_leaf(n.child1))
-      stack.push_back({n.child1, mine, 1});
-    if (!rtflat_is_leaf(n.child0))
-      stack.push_back({n.child0, mine, 0});
+      out[p.parentOut].child[p.slot] = mine;
+    for (uint32_t k = n; k-- > 0;) // pushed last = emitted first: child 0's subtree follows its parent
+      if (!rtflat_is_leaf(cand[k].ref))
+        stack.push_back({cand[k].ref, mine, k, p.depth + 1});
   }
   return rootOut;
 }
@@ -420,7 +502,7 @@ FlatScene flattenScene(const ScenePoolsView& pools, const FlattenOptions& opt)
   }
 
   // ---- build one BVH per model into a scratch pool, then emit pre-order
-  std::vector<rtflat_node> scratch(std::max(1u, totalTris));
+  std::vector<BinaryNode> scratch(std::max(1u, totalTris));
   std::atomic<uint32_t> nextNode{0};
   uint32_t threads = opt.threads ? opt.threads : std::thread::hardware_concurrency();
   threads = std::max(1u, std::min(threads, 16u));
@@ -442,14 +524,18 @@ FlatScene flattenScene(const ScenePoolsView& pools, const FlattenOptions& opt)
     bb.spareThreads = (int)threads - 1;
     float lo[3], hi[3];
     blasRoot[m] = bb.build(0, r.numIndices, lo, hi, 0);
-    deepest = std::max(deepest, bb.deepest.load());
   }
-  flat.nodes.reserve(nextNode.load());
+  flat.nodes.reserve(nextNode.load() / 2 + 1);
   for (size_t m = 0; m < numModels; ++m)
     if (blasRoot[m] != RTFLAT_INVALID)
-      blasRoot[m] = emitPreOrder(scratch.data(), blasRoot[m], flat.nodes);
+      blasRoot[m] = emitWide(scratch.data(), blasRoot[m], flat.nodes, deepest);
   if (flat.nodes.empty())
-    flat.nodes.push_back(rtflat_node{}); // keep the array non-empty for the uploader
+  {
+    // keep the array non-empty for the uploader: one node without children
+    rtflat_node none{};
+    quantiseNode(nullptr, 0, none);
+    flat.nodes.push_back(none);
+  }
   for (rtflat_model_node& mn : flat.modelNodes)
     if (mn.triCount > 0)
       mn.blas = blasRoot[mn.modelIndex];

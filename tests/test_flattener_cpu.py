@@ -70,26 +70,36 @@ def test_bvh_structure_is_sound(name):
         seen[first:first + count] += 1
         return pts.min(0), pts.max(0)
 
-    # iterative post-order containment check: each stored child box contains the child's content
+    def child_box(n, k):
+        step = np.ldexp(1.0, n["exp"].astype(np.int32) - 127)
+        return n["origin"] + n["qlo"][:, k] * step, n["origin"] + n["qhi"][:, k] * step
+
+    # post-order containment check: each stored (dequantised) child box strictly contains the child's content
     def check(ref, depth):
         if ref & 0x80000000:
             assert leaf_range(ref)[1] <= 8
             return box_of_leaf(ref) + (depth,)
         n = nodes[ref]
-        assert n["child0"] & 0x80000000 or n["child0"] > ref  # pre-order: children after parents
-        assert n["child1"] & 0x80000000 or n["child1"] > ref
-        lo0, hi0, d0 = check(int(n["child0"]), depth + 1)
-        lo1, hi1, d1 = check(int(n["child1"]), depth + 1)
-        assert np.all(n["lo0"] < lo0) and np.all(n["hi0"] > hi0), "child 0 box must be padded outward"
-        assert np.all(n["lo1"] < lo1) and np.all(n["hi1"] > hi1), "child 1 box must be padded outward"
-        return np.minimum(lo0, lo1), np.maximum(hi0, hi1), max(d0, d1)
+        assert 2 <= n["numChildren"] <= 4
+        lo, hi, deepest = np.full(3, np.inf), np.full(3, -np.inf), depth
+        for k in range(4):
+            c = int(n["child"][k])
+            if k >= n["numChildren"]:
+                assert c == 0xFFFFFFFF and np.all(n["qlo"][:, k] == 255) and np.all(n["qhi"][:, k] == 0)  # inverted: never hit
+                continue
+            assert c & 0x80000000 or c > ref  # pre-order: children after parents
+            clo, chi, d = check(c, depth + 1)
+            blo, bhi = child_box(n, k)
+            assert np.all(blo < clo) and np.all(bhi > chi), "a child box must contain the (padded) child"
+            lo, hi, deepest = np.minimum(lo, clo), np.maximum(hi, chi), max(deepest, d)
+        return lo, hi, deepest
 
     import sys
     sys.setrecursionlimit(10000)
     deepest = 0
     for mn in f["model_nodes"]:
         if mn["triCount"] > 0:
-            deepest = max(deepest, check(int(mn["blas"]), 0)[2])
+            deepest = max(deepest, check(int(mn["blas"]), 0)[2])  # depth counted in 4-wide nodes
     assert np.all(seen == 1)
     assert deepest == info.maxDepthBlas
     assert info.padAbs > 0 and info.numDegenerate == 0
