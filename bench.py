@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cube")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the extra instrumented frames (used under rocprofv3 --pmc)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the bounded CPU-baseline sample")
     args = ap.parse_args()
 
@@ -162,6 +163,9 @@ def main():
         return
 
     # ---- roofline of the dominant kernel: per-kernel HIP-event timing + algorithmic work counts, in separate untimed frames
+    if args.no_roofline:
+        print(json.dumps({"metric": "Mrays/s (primary+secondary)", "value": round(value, 2), "unit": "Mrays/s", "ms_per_step": round(ms_per_step, 4)}), flush=True)
+        return
     r.set_option("kernelTiming", 1)
     r.begin_frame(cam, width, height, spp)
     r.render_passes(0, spp)

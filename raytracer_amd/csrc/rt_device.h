@@ -225,14 +225,25 @@ RTD WideNode wideNodeSetup(float4 w0, float4 w2, float4 w3, vec3 invD, vec3 oi)
   n.nz = bz ? qhz : qlz, n.fz = bz ? qlz : qhz;
   return n;
 }
+// two children at a time: the six plane distances of children K and K+1 are three packed FMAs per side
+// (v_pk_fma_f32: two IEEE fp32 FMAs per instruction, same bits as two scalar ones)
+typedef float pair2 __attribute__((ext_vector_type(2)));
 template <int K>
-RTD void wideSlab(const WideNode& n, float& entry, float& exit)
+RTD void wideSlabPair(const WideNode& n, float& entry0, float& exit0, float& entry1, float& exit1)
 {
-  const float nx = rt::fma((float)((n.nx >> (8 * K)) & 0xffu), n.ax, n.bx), fx = rt::fma((float)((n.fx >> (8 * K)) & 0xffu), n.ax, n.bx);
-  const float ny = rt::fma((float)((n.ny >> (8 * K)) & 0xffu), n.ay, n.by), fy = rt::fma((float)((n.fy >> (8 * K)) & 0xffu), n.ay, n.by);
-  const float nz = rt::fma((float)((n.nz >> (8 * K)) & 0xffu), n.az, n.bz), fz = rt::fma((float)((n.fz >> (8 * K)) & 0xffu), n.az, n.bz);
-  entry = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
-  exit = fminf(fminf(fx, fy), fz);
+  const pair2 ax{n.ax, n.ax}, ay{n.ay, n.ay}, az{n.az, n.az}, bx{n.bx, n.bx}, by{n.by, n.by}, bz{n.bz, n.bz};
+  const pair2 qnx{(float)((n.nx >> (8 * K)) & 0xffu), (float)((n.nx >> (8 * K + 8)) & 0xffu)};
+  const pair2 qny{(float)((n.ny >> (8 * K)) & 0xffu), (float)((n.ny >> (8 * K + 8)) & 0xffu)};
+  const pair2 qnz{(float)((n.nz >> (8 * K)) & 0xffu), (float)((n.nz >> (8 * K + 8)) & 0xffu)};
+  const pair2 qfx{(float)((n.fx >> (8 * K)) & 0xffu), (float)((n.fx >> (8 * K + 8)) & 0xffu)};
+  const pair2 qfy{(float)((n.fy >> (8 * K)) & 0xffu), (float)((n.fy >> (8 * K + 8)) & 0xffu)};
+  const pair2 qfz{(float)((n.fz >> (8 * K)) & 0xffu), (float)((n.fz >> (8 * K + 8)) & 0xffu)};
+  const pair2 nx = __builtin_elementwise_fma(qnx, ax, bx), ny = __builtin_elementwise_fma(qny, ay, by), nz = __builtin_elementwise_fma(qnz, az, bz);
+  const pair2 fx = __builtin_elementwise_fma(qfx, ax, bx), fy = __builtin_elementwise_fma(qfy, ay, by), fz = __builtin_elementwise_fma(qfz, az, bz);
+  entry0 = fmaxf(fmaxf(nx.x, ny.x), fmaxf(nz.x, 0.0f));
+  exit0 = fminf(fminf(fx.x, fy.x), fz.x);
+  entry1 = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, 0.0f));
+  exit1 = fminf(fminf(fx.y, fy.y), fz.y);
 }
 // compare-exchange on (key, ref): afterwards ka <= kb.  Keys are the bit patterns of non-negative distances
 // (0xffffffff = missed), so unsigned order == distance order.

@@ -197,6 +197,7 @@ struct TraceArgs
   uint32_t chunkLen;         // dynamic mode: work items per fetch (multiple of 64)
   uint32_t refillAt;         // idle lanes that trigger a refill from the work list
   uint32_t leafTrigger;      // lanes waiting on a leaf that trigger a leaf step
+  uint32_t stealSpans;       // spans a wave may pull chunks from: its own first, then its neighbours'
   uint32_t* fetch;           // dynamic mode: kFetchShards counters, kFetchStride words apart, zeroed before the launch
   uint32_t depth;            // live[] value this launch serves (dense mode filter)
   uint32_t* spill;           // [spillCap][gridLanes]
@@ -206,7 +207,7 @@ struct TraceArgs
 };
 
 template <int MODE, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
+__global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs a)
 {
   __shared__ uint32_t sStack[kWavesPerBlock][kStackLds][64];
   __shared__ uint32_t sList[kWavesPerBlock][kChunk];
@@ -236,21 +237,25 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
   uint32_t runEnd = dynamic ? 0u : min(total, runNext + a.runLen);
   const uint32_t shard = blockIdx.x % kFetchShards;
   const uint32_t chunksPerShard = dynamic ? ((total + kFetchShards - 1) / kFetchShards + a.chunkLen - 1) / a.chunkLen : 0u;
-  bool exhausted = !dynamic; // dynamic mode: no more chunks in this wave's span
-  // pulls the next chunk of this wave's span into [runNext, runEnd)
+  bool exhausted = !dynamic; // dynamic mode: no more chunks anywhere
+  uint32_t shardsDone = 0;   // spans found empty so far: the wave's own first, then its neighbours' (work stealing)
+  // pulls the next chunk into [runNext, runEnd): from this wave's own span while it lasts, then from the other spans
+  // in turn (one attempt per call), so that an XCD whose image region was cheap helps the others out instead of idling
+  // through their tail.
   auto fetchChunk = [&]() {
+    const uint32_t sh = (shard + shardsDone) % kFetchShards;
     uint32_t c = 0;
     if (lane == 0)
-      c = atomicAdd(a.fetch + shard * kFetchStride, 1u);
+      c = atomicAdd(a.fetch + sh * kFetchStride, 1u);
     c = __builtin_amdgcn_readfirstlane(c);
-    const uint32_t base = (shard * chunksPerShard + c) * a.chunkLen;
-    if (c >= chunksPerShard || base >= total)
-      exhausted = true;
-    else
+    const uint32_t base = (sh * chunksPerShard + c) * a.chunkLen;
+    if (c < chunksPerShard && base < total)
     {
       runNext = base;
       runEnd = min(total, base + a.chunkLen);
     }
+    else if (++shardsDone >= a.stealSpans) // this span is empty: the next call tries the next one
+      exhausted = true;
   };
 
   // wave-uniform work-list state
@@ -631,10 +636,8 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
           nNodes++;
         const rtd::WideNode wn = rtd::wideNodeSetup(w0, w2, w3, invD, oi);
         float en0, ex0, en1, ex1, en2, ex2, en3, ex3;
-        rtd::wideSlab<0>(wn, en0, ex0);
-        rtd::wideSlab<1>(wn, en1, ex1);
-        rtd::wideSlab<2>(wn, en2, ex2);
-        rtd::wideSlab<3>(wn, en3, ex3);
+        rtd::wideSlabPair<0>(wn, en0, ex0, en1, ex1);
+        rtd::wideSlabPair<2>(wn, en2, ex2, en3, ex3);
         constexpr bool kClosest = isClosest(MODE);
         // sort the (at most four) children that were hit by entry distance; unused slots have inverted boxes
         uint32_t k0 = ((en0 <= ex0) && (!kClosest || en0 <= cull)) ? __float_as_uint(en0) : 0xffffffffu;
@@ -647,22 +650,23 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a)
         rtd::orderPair(k0, r0, k2, r2);
         rtd::orderPair(k1, r1, k3, r3);
         rtd::orderPair(k1, r1, k2, r2);
-        // push the farther ones, farthest first, so that the nearest of them is popped first
-        auto push = [&](uint32_t ref) {
-          if (sp - spLo == kStackLds)
+        // push the farther ones, farthest first, so that the nearest of them is popped first.  Misses sort to the
+        // end, so the valid flags are monotone (v1 >= v2 >= v3) and the three references can be written without
+        // branches: r3 at sp, r2 at sp+v3, r1 at sp+v3+v2 -- a reference that is not valid is overwritten by the next
+        // one or lands above the new top.  One spill check per step makes room for all three.
+        if (sp + 3 - spLo > kStackLds)
+        {
+          do
           {
             spill[(size_t)spLo * gridLanes] = stack[spLo % kStackLds][lane];
             spLo++;
-          }
-          stack[sp % kStackLds][lane] = ref;
-          sp++;
-        };
-        if (k3 != 0xffffffffu)
-          push(r3);
-        if (k2 != 0xffffffffu)
-          push(r2);
-        if (k1 != 0xffffffffu)
-          push(r1);
+          } while (sp + 3 - spLo > kStackLds);
+        }
+        const uint32_t v3 = k3 != 0xffffffffu, v2 = k2 != 0xffffffffu, v1 = k1 != 0xffffffffu;
+        stack[sp % kStackLds][lane] = r3;
+        stack[(sp + v3) % kStackLds][lane] = r2;
+        stack[(sp + v3 + v2) % kStackLds][lane] = r1;
+        sp += v3 + v2 + v1;
         if (k0 == 0xffffffffu)
           needPop = true;
         else if ((int)r0 < 0 && postponed == kNone)
@@ -1156,6 +1160,7 @@ struct rthip_ctx
   uint32_t spillCap = 1;         // per-lane spill entries the uploaded BVH can need
   uint32_t sparseCap = 0;        // capacity of listA / listB
   uint32_t tuneBlocks = 6;
+  uint32_t tuneSteal = 1; // spans a wave may pull chunks from (1 = its own only; stealing measured +4% on the 1M soup, -4% on the bunny: off)
   uint32_t tuneRefill = kRefillThreshold, tuneLeaf = kLeafTrigger;
   bool fusedPrimary = true;      // generate rays inside the depth-0 traversal kernel instead of storing them
   DevBuf<DeviceCounters> counters;
@@ -1271,6 +1276,7 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   a.anyOut = c->anyOut.p;
   a.refillAt = c->tuneRefill;
   a.leafTrigger = c->tuneLeaf;
+  a.stealSpans = c->tuneSteal;
   uint32_t blocks;
   constexpr bool staticMode = MODE == PRIMARY_GROUP;
   a.runLen = 0;
@@ -1488,12 +1494,14 @@ int rthip_create(int device, rthip_ctx** out)
   c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* t = getenv("RTHIP_TUNE")) // "refill,leaf[,blocksPerCU]" -- tuning experiments only
   {
-    unsigned r = 0, l = 0, b = 0;
-    const int n = sscanf(t, "%u,%u,%u", &r, &l, &b);
+    unsigned r = 0, l = 0, b = 0, st = 1;
+    const int n = sscanf(t, "%u,%u,%u,%u", &r, &l, &b, &st);
     if (n >= 2 && r >= 1 && r <= 64 && l >= 1 && l <= 64)
       c->tuneRefill = r, c->tuneLeaf = l;
     if (n >= 3 && b >= 1 && b <= 8)
       c->tuneBlocks = b;
+    if (n >= 4)
+      c->tuneSteal = st ? kFetchShards : 1u;
   }
   c->traceBlocks = (uint32_t)c->numCUs * c->tuneBlocks; // 6 blocks x 4 waves = 24 waves per CU: what 24 KB of LDS per block admits
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
