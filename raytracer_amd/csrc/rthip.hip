@@ -105,11 +105,15 @@ struct FrameGeom
 
 struct PathBuffers
 {
-  float4* rayO;  // o.xyz, w unused
-  float4* rayD;  // d.xyz, w = previous hit's face normal z
+  // Between shade(d) and the light fold of depth d+1 a path needs its hit position, the hit's face normal and its
+  // radiance; only a path that goes on bouncing also needs a direction and its throughput ("material").  The arrays are
+  // split along that line, so the last shaded depth writes 36 bytes per hit instead of 64.
+  float4* rayO;  // o.xyz, w = face normal x of the hit the ray leaves from
+  float4* rayD;  // d.xyz, w = material.x                        (not written by the last shaded depth)
   uint2* hit;    // x = float bits of t, y = triangle record index or RTFLAT_INVALID
-  float4* s0;    // radiance.xyz, material.x
-  float4* s1;    // material.y, material.z, previous normal.x, previous normal.y
+  float4* s0;    // radiance.xyz, w = face normal y of the previous hit
+  float2* s1;    // material.y, material.z                       (not written by the last shaded depth)
+  float* nz;     // face normal z of the previous hit
   uint8_t* live; // depth at which the path is waiting, kDead / kDeadZero when finished
   uint8_t* mask; // occlusion bits of the previous hit's shadow rays
 };
@@ -148,6 +152,30 @@ __device__ __forceinline__ bool pixelOf(const FrameGeom& g, uint32_t i, uint32_t
   w = (xy & 0xffffu) + bx * 8u + (l & 7u);
   h = (xy >> 16) + by * 8u + (l >> 3);
   return w < g.width && h < g.height;
+}
+
+// Adds the direct light of the hit a path has just left (CPUScene.cpp:31-49, lights in that order): directional lights
+// unless their shadow ray was occluded, then the point lights, unshadowed.  `o` is the hit position, nPrev its face normal.
+// One function for k_shade and the shadow kernel's final fold, so both produce the same bits.
+__device__ __forceinline__ vec3 foldLights(const Lights* lights, uint32_t occluded, vec3 o, vec3 nPrev, vec3 radiance)
+{
+  const vec3 albedo{0.0f, 1.0f, 0.0f}; // CPUScene.cpp:245
+  for (uint32_t l = 0; l < lights->numDir; ++l)
+  {
+    const rthip_dir_light& L = lights->dir[l];
+    if (!((occluded >> l) & 1u))
+      radiance = radiance + rtd::brdfEvaluate(albedo, nPrev, vec3{-L.direction[0], -L.direction[1], -L.direction[2]},
+                                              vec3{L.color[0], L.color[1], L.color[2]});
+  }
+  for (uint32_t l = 0; l < lights->numPoint; ++l)
+  {
+    const rthip_point_light& L = lights->point[l];
+    const vec3 lightDir = vec3{L.position[0], L.position[1], L.position[2]} - o;
+    const float dist = rt::length(lightDir);
+    const float illuminance = rt::maxRef(1 - dist / L.attenuation, 0.0f);
+    radiance = radiance + illuminance * rtd::brdfEvaluate(albedo, nPrev, lightDir, vec3{L.color[0], L.color[1], L.color[2]});
+  }
+  return radiance;
 }
 
 // ------------------------------------------------------------------------------------------------ set-up kernels
@@ -204,6 +232,9 @@ struct TraceArgs
   DeviceCounters* counters;
   float tmin, tmax;
   uint8_t* anyOut;           // ANYPROBE
+  uint32_t foldFinal;        // SHADOW: 1 = this is the last depth: fold the lights into the radiance and finish the path here
+  uint32_t aovDepths;        // SHADOW with foldFinal: shadow-flag AOV
+  uint8_t* aovShadow;
 };
 
 template <int MODE, bool COUNT>
@@ -275,7 +306,29 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
   bool needPop = false;          // the lane needs a new `cur` from its stack / the model tree
   uint32_t lightIdx = 0;         // SHADOW: which directional light this lane is testing
   uint32_t occluded = 0;         // SHADOW: result bits
+  float prevNx = 0.0f;           // SHADOW: rayO.w, the face normal x of the hit the shadow rays leave from
   uint32_t nRays = 0, nNodes = 0, nTris = 0, nNodeSteps = 0, nLeafSteps = 0;
+
+  // SHADOW: every light of this lane's path has been tested.  Normally the occlusion bits go to mask[] and the next
+  // shade launch folds the lights; at the last depth the fold happens right here (same function, same bits), which
+  // saves that launch and its re-read of the path state.
+  auto finishShadow = [&]() {
+    if (a.foldFinal)
+    {
+      const float4 s0 = a.pb.s0[slot];
+      const vec3 radiance = foldLights(a.lights, occluded, o, vec3{prevNx, s0.w, a.pb.nz[slot]}, vec3{s0.x, s0.y, s0.z});
+      if (a.depth - 1 < a.aovDepths)
+      {
+        uint32_t sidx, i;
+        sampleOf(a.geom, slot, sidx, i);
+        a.aovShadow[((size_t)sidx * a.aovDepths + (a.depth - 1)) * a.geom.numLocalPixels + i] = (uint8_t)occluded;
+      }
+      a.pb.s0[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+      a.pb.live[slot] = kDead;
+    }
+    else
+      a.pb.mask[slot] = (uint8_t)occluded;
+  };
 
   for (;;)
   {
@@ -286,8 +339,14 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
       // records together
       if (__ballot(active) == 0)
       {
+        // a primary miss contributes exactly +0: its slot is marked finished here and costs the shade kernel nothing
         if (groupValid)
-          a.pb.hit[slot] = make_uint2(__float_as_uint(best), bestRec);
+        {
+          const bool hitSomething = bestRec != RTFLAT_INVALID;
+          if (hitSomething)
+            a.pb.hit[slot] = make_uint2(__float_as_uint(best), bestRec);
+          a.pb.live[slot] = hitSomething ? (uint8_t)0 : kDeadZero;
+        }
         groupValid = false;
         if (runNext >= runEnd)
           break;
@@ -295,7 +354,10 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
         runNext += 64;
         uint32_t sidx, i, w, h;
         sampleOf(a.geom, slot, sidx, i);
-        if (slot < runEnd && pixelOf(a.geom, i, w, h))
+        const bool inImage = pixelOf(a.geom, i, w, h);
+        if (slot < runEnd && !inImage)
+          a.pb.live[slot] = kDeadZero; // padding pixel of a tile that overhangs the image
+        if (slot < runEnd && inImage)
         {
           const uint32_t samp = a.sampBegin + sidx;
           rtd::primaryRay(*a.cam, a.geom.width, a.geom.height, w, h, samp, rtd::rand01(w, h, samp), o, d);
@@ -335,7 +397,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
             slot = runNext + r;
             uint32_t sidx, i, w, h;
             sampleOf(a.geom, slot, sidx, i);
-            if (pixelOf(a.geom, i, w, h))
+            if (!pixelOf(a.geom, i, w, h))
+              a.pb.live[slot] = kDeadZero; // padding pixel of a tile that overhangs the image
+            else
             {
               const uint32_t samp = a.sampBegin + sidx;
               rtd::primaryRay(*a.cam, a.geom.width, a.geom.height, w, h, samp, rtd::rand01(w, h, samp), o, d);
@@ -411,6 +475,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
           {
             lightIdx = 0;
             occluded = 0;
+            prevNx = ro.w;
             const rthip_dir_light& L = a.lights->dir[0];
             d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]}; // Ray(position, -d.direction), CPUScene.cpp:34
           }
@@ -520,10 +585,18 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
             done = false;
           }
           else
-            a.pb.mask[slot] = (uint8_t)occluded;
+            finishShadow();
         }
-        else if (MODE == CLOSEST || MODE == PRIMARY)
+        else if (MODE == CLOSEST)
           a.pb.hit[slot] = make_uint2(__float_as_uint(best), bestRec);
+        else if (MODE == PRIMARY)
+        {
+          // a primary miss contributes exactly +0: its slot is marked finished here and costs the shade kernel nothing
+          const bool hitSomething = bestRec != RTFLAT_INVALID;
+          if (hitSomething)
+            a.pb.hit[slot] = make_uint2(__float_as_uint(best), bestRec);
+          a.pb.live[slot] = hitSomething ? (uint8_t)0 : kDeadZero;
+        }
         else if (MODE == ANYPROBE)
           a.anyOut[slot] = 0;
         // PRIMARY_GROUP: the group's hit records are stored together once every lane has finished
@@ -600,7 +673,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
               }
               else
               {
-                a.pb.mask[slot] = (uint8_t)occluded;
+                finishShadow();
                 active = false;
               }
             }
@@ -763,130 +836,105 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
         p = a.list[item];
     }
     else if (mine)
-    {
-      if (a.depth == 0 && a.primaryInRegs)
-      {
-        // no liveness bytes exist yet: every slot is a camera sample unless its pixel is outside the image
-      }
-      else
-        mine = a.pb.live[p] == depthTag;
-    }
+      mine = a.pb.live[p] == depthTag; // (the fused primary kernels write the depth-0 bytes: 0 = hit, kDeadZero = miss)
     bool survives = false;
     if (mine)
     {
       uint32_t s, i;
       sampleOf(a.g, p, s, i);
       uint32_t w = 0, h = 0;
-      bool havePixel = false;
       const bool regen = a.depth == 0 && a.primaryInRegs;
+      const bool folding = a.finalFold != 0;
       vec3 o{0, 0, 0}, d{0, 0, 1}, rnd{0, 0, 0};
-      float prevNz = 0.0f;
-      bool valid = true;
-      if (regen)
+      vec3 radiance{0.0f, 0.0f, 0.0f}, material{1.0f, 1.0f, 1.0f}; // Ray.h:7-8
+      if (!regen)
       {
-        // slots of pixels outside the image were never traced: their hit records are stale
-        valid = pixelOf(a.g, i, w, h);
-        havePixel = true;
-      }
-      else
-      {
-        const float4 ro = a.pb.rayO[p], rd = a.pb.rayD[p];
+        const float4 ro = a.pb.rayO[p];
         o = vec3{ro.x, ro.y, ro.z};
-        d = vec3{rd.x, rd.y, rd.z};
-        prevNz = rd.w;
-      }
-      if (!valid)
-        a.pb.live[p] = kDeadZero;
-      else
-      {
-        vec3 radiance{0.0f, 0.0f, 0.0f}, material{1.0f, 1.0f, 1.0f}; // Ray.h:7-8
+        if (!folding)
+        {
+          const float4 rd = a.pb.rayD[p];
+          d = vec3{rd.x, rd.y, rd.z};
+          if (a.depth > 0)
+            material.x = rd.w;
+        }
         if (a.depth > 0)
         {
-          const float4 s0 = a.pb.s0[p], s1 = a.pb.s1[p];
+          const float4 s0 = a.pb.s0[p];
           radiance = vec3{s0.x, s0.y, s0.z};
-          material = vec3{s0.w, s1.x, s1.y};
-          const vec3 nPrev{s1.z, s1.w, prevNz};
+          if (!folding)
+          {
+            const float2 s1 = a.pb.s1[p];
+            material.y = s1.x, material.z = s1.y;
+          }
+          // lights of the previous hit, whose position is this ray's origin (CPUScene.cpp:31-49)
           const uint32_t occl = a.lights->numDir ? a.pb.mask[p] : 0u;
-          // lights of the previous hit, whose position is this ray's origin (CPUScene.cpp:31-49, in that order)
-          for (uint32_t l = 0; l < a.lights->numDir; ++l)
-          {
-            const rthip_dir_light& L = a.lights->dir[l];
-            if (!((occl >> l) & 1u))
-              radiance = radiance + rtd::brdfEvaluate(albedo, nPrev, vec3{-L.direction[0], -L.direction[1], -L.direction[2]},
-                                                      vec3{L.color[0], L.color[1], L.color[2]});
-          }
-          for (uint32_t l = 0; l < a.lights->numPoint; ++l)
-          {
-            const rthip_point_light& L = a.lights->point[l];
-            const vec3 lightDir = vec3{L.position[0], L.position[1], L.position[2]} - o;
-            const float dist = rt::length(lightDir);
-            const float illuminance = rt::maxRef(1 - dist / L.attenuation, 0.0f);
-            radiance = radiance + illuminance * rtd::brdfEvaluate(albedo, nPrev, lightDir, vec3{L.color[0], L.color[1], L.color[2]});
-          }
+          radiance = foldLights(a.lights, occl, o, vec3{ro.w, s0.w, a.pb.nz[p]}, radiance);
           if (a.depth - 1 < a.aovDepths)
             a.aovShadow[((size_t)s * a.aovDepths + (a.depth - 1)) * a.g.numLocalPixels + i] = (uint8_t)occl;
         }
-        bool finished = a.finalFold != 0;
-        uint32_t rec = RTFLAT_INVALID;
-        float t = FLT_MAX;
-        if (!finished)
-        {
-          const uint2 hv = a.pb.hit[p];
-          t = __uint_as_float(hv.x);
-          rec = hv.y;
-          if (!(t < FLT_MAX)) // CPUScene.cpp:10
-            finished = true;
-          else
-          {
-            nHits++;
-            if (!havePixel)
-              pixelOf(a.g, i, w, h);
-            rnd = rtd::rand01(w, h, a.sampBegin + s);
-            if (regen) // the primary ray was never stored: same function, same bits (only paths that hit need it)
-              rtd::primaryRay(*a.cam, a.g.width, a.g.height, w, h, a.sampBegin + s, rnd, o, d);
-            const float pr = rt::maxRef(rt::maxRef(albedo.x, albedo.y), albedo.z); // :13
-            if (a.depth > 5)                                                      // :19 (depth >= maxDepth never reaches here)
-            {
-              if (rnd.z >= pr)
-                finished = true;
-              else
-                material = material / pr;
-            }
-          }
-        }
-        if (finished)
-        {
-          if (a.depth == 0)
-            a.pb.live[p] = kDeadZero; // a primary miss adds exactly +0 to the accumulator: nothing to store
-          else
-          {
-            a.pb.s0[p] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-            a.pb.live[p] = kDead;
-          }
-        }
+      }
+      bool finished = folding;
+      uint32_t rec = RTFLAT_INVALID;
+      float t = FLT_MAX;
+      if (!finished)
+      {
+        const uint2 hv = a.pb.hit[p];
+        t = __uint_as_float(hv.x);
+        rec = hv.y;
+        if (!(t < FLT_MAX)) // CPUScene.cpp:10
+          finished = true;
         else
         {
-          const float4* tp = reinterpret_cast<const float4*>(a.scene.tris + rec);
-          const float4 a2 = tp[2], a3 = tp[3];
-          const vec3 n{a2.y, a2.z, a2.w};
-          if (a.depth < a.aovDepths)
-            a.aovTri[((size_t)s * a.aovDepths + a.depth) * a.g.numLocalPixels + i] = __float_as_uint(a3.x);
-          const float payloadEmissive = a.depth == 0 ? 1.0f : 0.0f;                  // Ray.h:10, CPUScene.cpp:61
-          radiance = radiance + material * emissive * payloadEmissive;              // :27
-          material = material * albedo;                                             // :28
-          const vec3 position = o + d * t;                                          // :238
-          const vec3 normalLight = rt::dot(n, d) < 0 ? n : -n;                      // :240
-          vec3 nd{0.0f, 0.0f, 0.0f};
-          if (a.depth + 1 < a.maxDepth) // the bounce ray of the last shaded depth is never traced
-            nd = rtd::bounceDirection(normalLight, rnd);                            // :54-60
-          a.pb.rayO[p] = make_float4(position.x, position.y, position.z, 0.0f);
-          a.pb.rayD[p] = make_float4(nd.x, nd.y, nd.z, n.z);
-          a.pb.s0[p] = make_float4(radiance.x, radiance.y, radiance.z, material.x);
-          a.pb.s1[p] = make_float4(material.y, material.z, n.x, n.y);
-          a.pb.live[p] = (uint8_t)(a.depth + 1);
-          nAlive++;
-          survives = true;
+          nHits++;
+          pixelOf(a.g, i, w, h);
+          rnd = rtd::rand01(w, h, a.sampBegin + s);
+          if (regen) // the primary ray was never stored: same function, same bits (only paths that hit need it)
+            rtd::primaryRay(*a.cam, a.g.width, a.g.height, w, h, a.sampBegin + s, rnd, o, d);
+          const float pr = rt::maxRef(rt::maxRef(albedo.x, albedo.y), albedo.z); // :13
+          if (a.depth > 5)                                                      // :19 (depth >= maxDepth never reaches here)
+          {
+            if (rnd.z >= pr)
+              finished = true;
+            else
+              material = material / pr;
+          }
         }
+      }
+      if (finished)
+      {
+        if (a.depth == 0)
+          a.pb.live[p] = kDeadZero; // a primary miss adds exactly +0 to the accumulator: nothing to store
+        else
+        {
+          a.pb.s0[p] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+          a.pb.live[p] = kDead;
+        }
+      }
+      else
+      {
+        const float4* tp = reinterpret_cast<const float4*>(a.scene.tris + rec);
+        const float4 a2 = tp[2], a3 = tp[3];
+        const vec3 n{a2.y, a2.z, a2.w};
+        if (a.depth < a.aovDepths)
+          a.aovTri[((size_t)s * a.aovDepths + a.depth) * a.g.numLocalPixels + i] = __float_as_uint(a3.x);
+        const float payloadEmissive = a.depth == 0 ? 1.0f : 0.0f;                  // Ray.h:10, CPUScene.cpp:61
+        radiance = radiance + material * emissive * payloadEmissive;              // :27
+        material = material * albedo;                                             // :28
+        const vec3 position = o + d * t;                                          // :238
+        a.pb.rayO[p] = make_float4(position.x, position.y, position.z, n.x);
+        a.pb.s0[p] = make_float4(radiance.x, radiance.y, radiance.z, n.y);
+        a.pb.nz[p] = n.z;
+        if (a.depth + 1 < a.maxDepth) // the last shaded depth traces no bounce ray: neither direction nor throughput is kept
+        {
+          const vec3 normalLight = rt::dot(n, d) < 0 ? n : -n;                    // :240
+          const vec3 nd = rtd::bounceDirection(normalLight, rnd);                 // :54-60
+          a.pb.rayD[p] = make_float4(nd.x, nd.y, nd.z, material.x);
+          a.pb.s1[p] = make_float2(material.y, material.z);
+        }
+        a.pb.live[p] = (uint8_t)(a.depth + 1);
+        nAlive++;
+        survives = true;
       }
     }
     if (SPARSE)
@@ -1149,7 +1197,9 @@ struct rthip_ctx
   std::vector<uint32_t> hostTileIds, hostTileXY;
   DevBuf<uint32_t> tileIds;
   DevBuf<CameraConsts> camConsts;
-  DevBuf<float4> rayO, rayD, s0, s1;
+  DevBuf<float4> rayO, rayD, s0;
+  DevBuf<float2> s1;
+  DevBuf<float> nz;
   DevBuf<uint2> hit;
   DevBuf<uint8_t> live, mask, anyOut;
   DevBuf<float> acc, img, rowScratch;
@@ -1188,7 +1238,7 @@ DeviceScene devScene(const rthip_ctx* c)
 PathBuffers pathBuffers(const rthip_ctx* c)
 {
   PathBuffers pb;
-  pb.rayO = c->rayO.p, pb.rayD = c->rayD.p, pb.hit = c->hit.p, pb.s0 = c->s0.p, pb.s1 = c->s1.p, pb.live = c->live.p, pb.mask = c->mask.p;
+  pb.rayO = c->rayO.p, pb.rayD = c->rayD.p, pb.hit = c->hit.p, pb.s0 = c->s0.p, pb.s1 = c->s1.p, pb.nz = c->nz.p, pb.live = c->live.p, pb.mask = c->mask.p;
   return pb;
 }
 
@@ -1236,7 +1286,7 @@ void dynamicGeometry(const rthip_ctx* c, uint32_t total, uint32_t& blocks, uint3
 int ensurePathBuffers(rthip_ctx* c, size_t numSlots)
 {
   int rc;
-  if ((rc = c->rayO.ensure(numSlots)) || (rc = c->rayD.ensure(numSlots)) || (rc = c->s0.ensure(numSlots)) || (rc = c->s1.ensure(numSlots)) ||
+  if ((rc = c->rayO.ensure(numSlots)) || (rc = c->rayD.ensure(numSlots)) || (rc = c->s0.ensure(numSlots)) || (rc = c->s1.ensure(numSlots)) || (rc = c->nz.ensure(numSlots)) ||
       (rc = c->hit.ensure(numSlots)) || (rc = c->live.ensure(numSlots + 64)) || (rc = c->mask.ensure(numSlots)))
     return rc;
   uint32_t blocks, runLen;
@@ -1256,7 +1306,7 @@ int ensurePathBuffers(rthip_ctx* c, size_t numSlots)
 // length is at most `bound`
 template <int MODE>
 int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBegin, float tmin, float tmax, const uint32_t* list = nullptr,
-                uint32_t bound = 0)
+                uint32_t bound = 0, bool foldFinal = false)
 {
   TraceArgs a;
   a.scene = devScene(c);
@@ -1277,6 +1327,9 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   a.refillAt = c->tuneRefill;
   a.leafTrigger = c->tuneLeaf;
   a.stealSpans = c->tuneSteal;
+  a.foldFinal = foldFinal ? 1u : 0u;
+  a.aovDepths = c->aovDepths;
+  a.aovShadow = c->aovShadow.p;
   uint32_t blocks;
   constexpr bool staticMode = MODE == PRIMARY_GROUP;
   a.runLen = 0;
@@ -1363,8 +1416,11 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count)
     const uint32_t* list = sparse ? ((d & 1u) ? c->listB.p : c->listA.p) : nullptr;
     uint32_t* listNext = (d & 1u) ? c->listA.p : c->listB.p;
     int rc;
-    if (d > 0 && haveDirLights && (rc = launchTrace<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, bound)))
+    // shadow rays of the hits of depth d-1; at the last depth the same launch also folds the lights and finishes the paths
+    if (d > 0 && haveDirLights && (rc = launchTrace<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, bound, last)))
       return rc;
+    if (last && haveDirLights)
+      break;
     if (!last)
     {
       // coherent primary rays over a scene of a few nodes cost the same everywhere: static 64-slot groups, no atomics;
@@ -1520,7 +1576,7 @@ int rthip_destroy(rthip_ctx* c)
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   c->modelNodes.release(), c->nodes.release(), c->tris.release(), c->lights.release(), c->tileIds.release(), c->camConsts.release();
-  c->rayO.release(), c->rayD.release(), c->s0.release(), c->s1.release(), c->hit.release(), c->live.release(), c->mask.release();
+  c->rayO.release(), c->rayD.release(), c->s0.release(), c->s1.release(), c->nz.release(), c->hit.release(), c->live.release(), c->mask.release();
   c->anyOut.release(), c->acc.release(), c->img.release(), c->rowScratch.release(), c->aovTri.release(), c->aovShadow.release();
   c->spill.release(), c->fetch.release(), c->listA.release(), c->listB.release(), c->counters.release();
   (void)hipEventDestroy(c->evA), (void)hipEventDestroy(c->evB), (void)hipEventDestroy(c->evK0), (void)hipEventDestroy(c->evK1);
