@@ -190,18 +190,21 @@ def main():
     dominant = max(ktimes, key=lambda k: ktimes[k][0])
     k_ms, k_launches = ktimes[dominant]
     achieved = alg_bytes[dominant] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    traffic = None
+    # HBM bytes per launch and VALU issue utilisation come from the committed rocprofv3 PMC passes of this same command
+    # (tools/profile_pmc.sh -> profiles/traffic.json); counters cannot be read from inside the process
+    traffic = valu_util = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             traffic = tj.get(args.workload, {}).get(dominant)
+            valu_util = tj.get("_valu_issue_utilisation", {}).get(args.workload, {}).get(dominant)
         except Exception:
-            traffic = None
+            traffic = valu_util = None
     roofline = {"bound": "hbm", "kernel": {"extend": "k_trace<PRIMARY|CLOSEST> (extend)", "shadow": "k_trace<SHADOW>", "generate": "k_generate",
                                            "shade": "k_shade", "accumulate": "k_accumulate", "compact": "k_compact"}[dominant],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes[dominant] / max(1, k_launches), 1),
+                "traffic": traffic, "valu_issue_utilisation": valu_util, "algorithmic_bytes_per_launch": round(alg_bytes[dominant] / max(1, k_launches), 1),
                 "avg_launch_ms": round(k_ms / max(1, k_launches), 5), "launches_per_step": k_launches,
                 "nodes_per_extend_ray": round(wc["nodesVisitedExtend"] / max(1, n_ext), 3),
                 "tris_per_extend_ray": round(wc["trisTestedExtend"] / max(1, n_ext), 3),

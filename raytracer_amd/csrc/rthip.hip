@@ -543,7 +543,12 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
             const rtflat_model_node* mn = modelNodes + mk;
             if (COUNT)
               nNodes++;
-            if (!rtd::refSlab(mn->lo, mn->hi, o, rt::rcp3(d) /* AABB.h:49 */, a.tmin, a.tmax))
+            // AABB.h:49 divides by the direction: invD is that quotient unless it was clamped (axis-parallel rays, rare),
+            // so the three IEEE divisions are repeated only for a wave that holds such a ray
+            vec3 invRef = invD;
+            if (fabsf(invD.x) == 1e18f || fabsf(invD.y) == 1e18f || fabsf(invD.z) == 1e18f)
+              invRef = rt::rcp3(d);
+            if (!rtd::refSlab(mn->lo, mn->hi, o, invRef, a.tmin, a.tmax))
             {
               mk += mn->subtreeSize; // skip the subtree
               continue;

@@ -53,6 +53,7 @@ def main():
                 calls[k][c].add((path, row["Dispatch_Id"]))
     out = {}
     traffic_sum = defaultdict(lambda: [0.0, 0.0, 0, 0])  # key -> [fetch KiB, write KiB, fetch dispatches, write dispatches]
+    valu_sum = defaultdict(lambda: [0.0, 0, 0.0, 0])     # key -> [SQ_INSTS_VALU, dispatches, GRBM_GUI_ACTIVE, dispatches]
     for k, cs in per.items():
         if not k.startswith("k_"):
             continue  # torch / runtime kernels
@@ -84,8 +85,20 @@ def main():
             if "WRITE_SIZE" in cs:
                 t[1] += cs["WRITE_SIZE"]
                 t[3] += n["WRITE_SIZE"]
+            v = valu_sum[bk]
+            if "SQ_INSTS_VALU" in cs:
+                v[0] += cs["SQ_INSTS_VALU"]
+                v[1] += n["SQ_INSTS_VALU"]
+            if "GRBM_GUI_ACTIVE" in cs:
+                v[2] += cs["GRBM_GUI_ACTIVE"]
+                v[3] += n["GRBM_GUI_ACTIVE"]
     traffic = {k: round(2048.0 * t[0] / t[2] + 1024.0 * t[1] / t[3], 1) for k, t in traffic_sum.items() if t[2] and t[3]}
     out["_hbm_bytes_per_launch"] = traffic
+    # VALU issue utilisation: wave-instructions x 4 cycles (a wave64 op occupies its 16-lane SIMD for 4 cycles; quarter-rate
+    # ops for longer, so this is a lower bound) over the SIMD-cycles of the launch.  GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+    NUM_SIMD, NUM_XCD = 256 * 4, 8
+    valu = {k: round((v[0] / v[1]) * 4.0 / (NUM_SIMD * (v[2] / v[3]) / NUM_XCD), 4) for k, v in valu_sum.items() if v[1] and v[3] and v[2] > 0}
+    out["_valu_issue_utilisation"] = valu
     print(json.dumps(out, indent=1, sort_keys=True))
     if len(sys.argv) >= 5 and sys.argv[2] == "--traffic":
         workload, path = sys.argv[3], sys.argv[4]
@@ -93,6 +106,7 @@ def main():
         doc["_note"] = ("HBM bytes per launch from rocprofv3 PMC passes (tools/profile_pmc.sh): 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, "
                         "averaged over the launches of each kernel family in bench.py runs of the named workload")
         doc[workload] = traffic
+        doc.setdefault("_valu_issue_utilisation", {})[workload] = valu
         json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
 
 
