@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cube")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dynamic", action="store_true", help="N>1: tiles from a shared cursor (dynamic rebalancing) instead of static round-robin")
+    ap.add_argument("--tile-batch", type=int, default=16, help="--dynamic: tiles taken from the cursor at a time")
     ap.add_argument("--no-roofline", action="store_true", help="skip the extra instrumented frames (used under rocprofv3 --pmc)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the bounded CPU-baseline sample")
     args = ap.parse_args()
@@ -109,10 +111,23 @@ def main():
     full_frame = torch.zeros((height, width, 3), dtype=torch.float32, device=f"cuda:{local_rank}") if (world > 1 and rank == 0) else None
     gather_ms = []
 
+    tiles_total = int(sum(len(a) for a in assignment))
+    dynamic = args.dynamic and world > 1
+    queue = None
+    if dynamic:
+        queue = rdist.TileQueue(rdist.make_queue_store(dist, rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1")), tiles_total, args.tile_batch)
+        # a rank may end up with any number of tiles: room for all of them
+        local_buf = torch.empty((tiles_total * ts * ts, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
+    frame_no = [0]
+    tile_counts, finish_times = [], []
+
+    step_rays = np.zeros(4)  # dynamic mode: rays of the current step, summed over its tile batches
+
     def step():
-        r.begin_frame(cam, width, height, spp)
-        r.render_passes(0, spp)
-        if world > 1:
+        if not dynamic:
+            r.begin_frame(cam, width, height, spp)
+            r.render_passes(0, spp)
+        if world > 1 and not dynamic:
             t0 = time.perf_counter()
             rc = hl.rthip_copy_accumulator_to(ctx, local_buf.data_ptr(), n_local_floats)
             assert rc == 0, ra.capi.error_string(rc)
@@ -123,6 +138,37 @@ def main():
                 bufs = [b.to(f"cuda:{local_rank}") for b in bufs] if rank == 0 else None
             if rank == 0:
                 for src, tiles in zip(bufs, assignment):
+                    rc = hl.rthip_untile(ctx, src.data_ptr(), ra.capi._up(tiles), len(tiles), full_frame.data_ptr())
+                    assert rc == 0, ra.capi.error_string(rc)
+            torch.cuda.synchronize()
+            gather_ms.append((time.perf_counter() - t0) * 1e3)
+        if dynamic:
+            # tiles come from the shared cursor in batches; each batch is a frame of its own over just those tiles
+            queue.new_frame(frame_no[0])
+            frame_no[0] += 1
+            mine, filled = [], 0
+            step_rays[:] = 0
+            while (batch := queue.next_batch()) is not None:
+                r.set_tiles(batch)
+                r.begin_frame(cam, width, height, spp)
+                r.render_passes(0, spp)
+                n = len(batch) * ts * ts * 3
+                rc = hl.rthip_copy_accumulator_to(ctx, local_buf.data_ptr() + filled * 4, n)
+                assert rc == 0, ra.capi.error_string(rc)
+                filled += n
+                mine.extend(int(t) for t in batch)
+                bc = r.counters()
+                step_rays[:] += [bc["extendPrimary"] + bc["extendSecondary"] + bc["shadow"], bc["extendPrimary"], bc["extendSecondary"], bc["shadow"]]
+            finish_times.append(time.perf_counter())
+            tile_counts.append(len(mine))
+            t0 = time.perf_counter()
+            local = local_buf[: filled // 3]
+            got = rdist.gather_dynamic(local if backend == "nccl" else local.cpu(), mine, rank, world, dist, ts * ts)
+            if rank == 0:
+                for tiles, src in got:
+                    if len(tiles) == 0:
+                        continue
+                    src = src.to(f"cuda:{local_rank}").contiguous()
                     rc = hl.rthip_untile(ctx, src.data_ptr(), ra.capi._up(tiles), len(tiles), full_frame.data_ptr())
                     assert rc == 0, ra.capi.error_string(rc)
             torch.cuda.synchronize()
@@ -144,6 +190,8 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     cnt = r.counters()  # totals of the LAST frame (begin_frame resets them)
+    if dynamic:
+        cnt = {"extendPrimary": step_rays[1], "extendSecondary": step_rays[2], "shadow": step_rays[3]}
     rays_local = cnt["extendPrimary"] + cnt["extendSecondary"] + cnt["shadow"]
     t = torch.tensor([elapsed, float(rays_local), float(cnt["extendPrimary"]), float(cnt["extendSecondary"]), float(cnt["shadow"])],
                      dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
@@ -154,6 +202,16 @@ def main():
         elapsed = float(tmax[0])
     rays_frame = float(t[1])
     ms_per_step = elapsed / args.steps * 1e3
+    balance = None
+    if dynamic:
+        # per-rank tile counts of the last step and the idle tail: how long the first rank to run dry waited for the last
+        mine_stats = [tile_counts[-1] if tile_counts else 0, finish_times[-args.steps:] if finish_times else []]
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine_stats)
+        ends = np.array([e[1] for e in everyone], dtype=np.float64)  # [rank][step]
+        balance = {"tiles_per_rank_last_step": [int(e[0]) for e in everyone], "tile_batch": args.tile_batch,
+                   "idle_tail_ms_mean": round(float(np.mean(ends.max(0) - ends.min(0)) * 1e3), 4) if ends.size else None}
+        r.set_tiles(assignment[rank])
     value = rays_frame / (ms_per_step * 1e-3) / 1e6
 
     if rank != 0:
@@ -248,7 +306,7 @@ def main():
            "config": {"workload": wl["name"], "width": width, "height": height, "spp": spp, "max_depth": max_depth,
                       "tris": int(flat["info"].numTris), "bvh_nodes": int(flat["info"].numNodes),
                       "rays_per_step": int(rays_frame), "primary": int(t[2]), "secondary_extend": int(t[3]), "shadow": int(t[4]),
-                      "parallelism": f"tiles64-rr-x{world}-{backend}" if world > 1 else "single",
+                      "parallelism": (f"tiles64-{'dynamic' if dynamic else 'rr'}-x{world}-{backend}" if world > 1 else "single"), "balance": balance,
                       "gather_ms": round(float(np.mean(gather_ms)), 4) if gather_ms else None},
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)

@@ -74,3 +74,77 @@ def gather_tiles(local, assignment, rank, world_size, dist, device=None):
     bufs = [torch.empty_like(local) for _ in range(world_size)] if rank == 0 else None
     dist.gather(local, bufs, dst=0)
     return bufs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Dynamic tile ownership: over-decomposed tiles handed out from one shared cursor, so a GPU whose
+# tiles were cheap takes more of them instead of idling through the others' tail.  A whole tile (all its samples) is
+# still rendered by one rank, so per-pixel accumulation order -- and therefore every bit of the frame -- is unchanged.
+
+class TileQueue:
+    """A cursor over the row-major tile list shared by all ranks through a torch.distributed store (the store's `add` is
+    atomic).  No data-path collective is involved: ranks only ever touch the counter."""
+
+    KEY = "rt_tile_cursor"
+
+    def __init__(self, store, num_tiles, batch):
+        assert batch >= 1
+        self.store, self.num_tiles, self.batch = store, int(num_tiles), int(batch)
+        self.key = self.KEY
+
+    def new_frame(self, frame_index):
+        """A fresh cursor for the next frame (every rank calls it with the same index; no reset race: a new key)."""
+        self.key = "%s_%d" % (self.KEY, int(frame_index))
+
+    def next_batch(self):
+        """The next `batch` tile ids as a uint32 array, fewer at the end of the list, None when the list is exhausted."""
+        end = int(self.store.add(self.key, self.batch))
+        start = end - self.batch
+        if start >= self.num_tiles:
+            return None
+        return np.arange(start, min(end, self.num_tiles), dtype=np.uint32)
+
+
+def make_queue_store(dist, rank, world_size, host="127.0.0.1"):
+    """A TCPStore of its own for the tile cursor (rank 0 serves it); the port is agreed through the process group."""
+    import socket
+    import torch.distributed as tdist
+    port = [0]
+    if rank == 0:
+        with socket.socket() as s:
+            s.bind((host, 0))
+            port[0] = s.getsockname()[1]
+    if world_size > 1:
+        dist.broadcast_object_list(port, src=0)
+    return tdist.TCPStore(host, port[0], world_size, is_master=(rank == 0), wait_for_workers=False)
+
+
+def gather_dynamic(local, tile_ids, rank, world_size, dist, tile_pixels):
+    """Gathers per-rank tile-major buffers of DIFFERENT lengths to rank 0: the tile-id lists first (padded with -1), then the
+    pixel buffers padded to the longest.  Returns [(tile_ids, buffer)] per rank on rank 0, None elsewhere."""
+    import torch
+    tile_ids = np.asarray(tile_ids, dtype=np.int64)
+    counts = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world_size)]
+    mine = torch.tensor([len(tile_ids)], dtype=torch.int64, device=local.device)
+    if world_size > 1:
+        dist.all_gather(counts, mine)
+    else:
+        counts = [mine]
+    most = max(1, max(int(c.item()) for c in counts))
+    ids = torch.full((most,), -1, dtype=torch.int64, device=local.device)
+    ids[: len(tile_ids)] = torch.from_numpy(tile_ids).to(local.device)
+    buf = torch.zeros((most * tile_pixels, 3), dtype=local.dtype, device=local.device)
+    buf[: local.shape[0]] = local
+    if world_size == 1:
+        return [(tile_ids.astype(np.uint32), buf[: len(tile_ids) * tile_pixels])]
+    id_bufs = [torch.empty_like(ids) for _ in range(world_size)] if rank == 0 else None
+    px_bufs = [torch.empty_like(buf) for _ in range(world_size)] if rank == 0 else None
+    dist.gather(ids, id_bufs, dst=0)
+    dist.gather(buf, px_bufs, dst=0)
+    if rank != 0:
+        return None
+    out = []
+    for c, i, b in zip(counts, id_bufs, px_bufs):
+        k = int(c.item())
+        out.append((i[:k].cpu().numpy().astype(np.uint32), b[: k * tile_pixels]))
+    return out

@@ -74,3 +74,67 @@ def test_two_rank_render_equals_single_process(tmp_path):
     spec = scenes.cube_scene()
     want = spec.build_oracle().render(spec.oracle_camera(), 200, 136, 2, max_depth=12, workers=4)["accumulator"]
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def _dynamic_worker(rank, world, port, out_path):
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = scenes.cube_scene()
+    W, H, N, ts = 200, 136, 2, 64
+    tx, ty = rdist.tile_grid(W, H, ts)
+    queue = rdist.TileQueue(rdist.make_queue_store(dist, rank, world), tx * ty, batch=2)
+    o = spec.build_oracle()
+    frame = np.zeros((H, W, 3), np.float32)
+    mine = []
+    while (batch := queue.next_batch()) is not None:
+        for t in batch:
+            x0, y0 = int(t % tx) * ts, int(t // tx) * ts
+            r = o.render(spec.oracle_camera(), W, H, N, max_depth=12, window=(x0, y0, min(W, x0 + ts), min(H, y0 + ts)), workers=2)
+            frame[y0:y0 + ts, x0:x0 + ts] = r["accumulator"][y0:y0 + ts, x0:x0 + ts]
+        mine.extend(int(t) for t in batch)
+        if rank == 1:
+            time.sleep(0.3)  # a slow rank: the other one must end up with more tiles
+    local = torch.from_numpy(rdist.to_tile_major(frame, np.asarray(mine, np.uint32), ts)) if mine else torch.zeros((0, 3))
+    got = rdist.gather_dynamic(local, mine, rank, world, dist, ts * ts)
+    if rank == 0:
+        tiles = [g[0] for g in got]
+        full = rdist.assemble([g[1].numpy() for g in got], tiles, W, H, ts)
+        np.savez(out_path, frame=full, owner0=tiles[0], owner1=tiles[1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dynamic_tile_queue_two_ranks_equals_single_process(tmp_path):
+    """SURVEY 8d config 5's scheduling: tiles come from one shared cursor; every tile is rendered exactly once, the slower
+    rank takes fewer, and the assembled frame is still bit-identical to a single-process render."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dyn.npz")
+    mp.start_processes(_dynamic_worker, args=(2, port, out), nprocs=2, join=True, start_method="spawn")
+    z = np.load(out)
+    tx, ty = rdist.tile_grid(200, 136, 64)
+    assert sorted(z["owner0"].tolist() + z["owner1"].tolist()) == list(range(tx * ty))
+    assert len(z["owner0"]) > len(z["owner1"])
+    spec = scenes.cube_scene()
+    want = spec.build_oracle().render(spec.oracle_camera(), 200, 136, 2, max_depth=12, workers=4)["accumulator"]
+    assert np.array_equal(z["frame"].view(np.uint32), want.view(np.uint32))
+
+
+def test_tile_queue_single_process_hands_out_every_tile_once():
+    import torch.distributed as tdist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    store = tdist.TCPStore("127.0.0.1", port, 1, is_master=True, wait_for_workers=False)
+    q = rdist.TileQueue(store, 11, 4)
+    got = []
+    while (b := q.next_batch()) is not None:
+        got.append(b.tolist())
+    assert got == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10]]
