@@ -1181,6 +1181,8 @@ struct rthip_ctx
 {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr; // second stream for the shadow launch of a depth (see renderBatch)
+  hipEvent_t evFork = nullptr, evJoin = nullptr;
   hipEvent_t evA = nullptr, evB = nullptr, evK0 = nullptr, evK1 = nullptr;
   int numCUs = 256;
   uint32_t traceBlocks = 2048; // persistent grid of the dynamic mode
@@ -1211,10 +1213,12 @@ struct rthip_ctx
   DevBuf<uint32_t> aovTri;
   DevBuf<uint8_t> aovShadow;
   DevBuf<uint32_t> spill, fetch;
+  DevBuf<uint32_t> spill2;       // stack spill area of launches on stream2
   DevBuf<uint32_t> listA, listB; // sparse-mode slot lists (even / odd depth)
   uint32_t spillCap = 1;         // per-lane spill entries the uploaded BVH can need
   uint32_t sparseCap = 0;        // capacity of listA / listB
   uint32_t tuneBlocks = 6;
+  uint32_t overlapShadow = 1;    // run a depth's shadow and closest-hit launches on two streams (their tails overlap)
   uint32_t tuneSteal = 1; // spans a wave may pull chunks from (1 = its own only; stealing measured +4% on the 1M soup, -4% on the bunny: off)
   uint32_t tuneRefill = kRefillThreshold, tuneLeaf = kLeafTrigger;
   bool fusedPrimary = true;      // generate rays inside the depth-0 traversal kernel instead of storing them
@@ -1297,7 +1301,7 @@ int ensurePathBuffers(rthip_ctx* c, size_t numSlots)
   uint32_t blocks, runLen;
   staticGeometry((uint32_t)numSlots, blocks, runLen);
   blocks = std::max(blocks, c->traceBlocks);
-  if ((rc = c->spill.ensure((size_t)c->spillCap * blocks * kBlock)))
+  if ((rc = c->spill.ensure((size_t)c->spillCap * blocks * kBlock)) || (rc = c->spill2.ensure((size_t)c->spillCap * blocks * kBlock)))
     return rc;
   if ((rc = c->fetch.ensure((size_t)kMaxTraceLaunches * kFetchShards * kFetchStride)))
     return rc;
@@ -1311,7 +1315,7 @@ int ensurePathBuffers(rthip_ctx* c, size_t numSlots)
 // length is at most `bound`
 template <int MODE>
 int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBegin, float tmin, float tmax, const uint32_t* list = nullptr,
-                uint32_t bound = 0, bool foldFinal = false)
+                uint32_t bound = 0, bool foldFinal = false, bool sideStream = false)
 {
   TraceArgs a;
   a.scene = devScene(c);
@@ -1324,7 +1328,7 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   a.list = list;
   a.listCount = list ? &c->counters.p->listCount[depth] : nullptr;
   a.depth = depth;
-  a.spill = c->spill.p;
+  a.spill = sideStream ? c->spill2.p : c->spill.p;
   a.counters = c->counters.p;
   a.tmin = tmin;
   a.tmax = tmax;
@@ -1351,11 +1355,12 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   }
   if ((size_t)c->spillCap * blocks * kBlock > c->spill.n)
     return RTHIP_E_LIMIT;
-  KernelTimer kt(c, isClosest(MODE) ? 1 : 3);
+  hipStream_t stream = sideStream ? c->stream2 : c->stream;
+  KernelTimer kt(c, isClosest(MODE) ? 1 : 3); // (the side stream is only used when kernel timing is off)
   if (c->countWork)
-    hipLaunchKernelGGL((k_trace<MODE, true>), dim3(blocks), dim3(kBlock), 0, c->stream, a);
+    hipLaunchKernelGGL((k_trace<MODE, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
   else
-    hipLaunchKernelGGL((k_trace<MODE, false>), dim3(blocks), dim3(kBlock), 0, c->stream, a);
+    hipLaunchKernelGGL((k_trace<MODE, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -1422,8 +1427,21 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count)
     uint32_t* listNext = (d & 1u) ? c->listA.p : c->listB.p;
     int rc;
     // shadow rays of the hits of depth d-1; at the last depth the same launch also folds the lights and finishes the paths
-    if (d > 0 && haveDirLights && (rc = launchTrace<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, bound, last)))
+    // A depth's shadow launch (reads rayO, writes mask) and closest-hit launch (reads rayO/rayD, writes hit) are
+    // independent, and each ends in a tail where a few long rays keep a few waves busy.  On two streams the second
+    // launch's blocks move in as the first one's run dry, so one tail per depth is hidden; shade(d) joins both.
+    const bool side = d > 0 && !last && haveDirLights && c->overlapShadow && !c->kernelTiming;
+    if (side)
+    {
+      HIPCHK(hipEventRecord(c->evFork, c->stream));
+      HIPCHK(hipStreamWaitEvent(c->stream2, c->evFork, 0));
+    }
+    if (d > 0 && haveDirLights && (rc = launchTrace<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, bound, last, side)))
       return rc;
+    if (side)
+    {
+      HIPCHK(hipEventRecord(c->evJoin, c->stream2));
+    }
     if (last && haveDirLights)
       break;
     if (!last)
@@ -1439,6 +1457,8 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count)
       if (rc)
         return rc;
     }
+    if (side)
+      HIPCHK(hipStreamWaitEvent(c->stream, c->evJoin, 0));
     sa.depth = d;
     sa.finalFold = last ? 1u : 0u;
     sa.list = list;
@@ -1555,14 +1575,16 @@ int rthip_create(int device, rthip_ctx** out)
   c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* t = getenv("RTHIP_TUNE")) // "refill,leaf[,blocksPerCU]" -- tuning experiments only
   {
-    unsigned r = 0, l = 0, b = 0, st = 1;
-    const int n = sscanf(t, "%u,%u,%u,%u", &r, &l, &b, &st);
+    unsigned r = 0, l = 0, b = 0, st = 1, ov = 1;
+    const int n = sscanf(t, "%u,%u,%u,%u,%u", &r, &l, &b, &st, &ov);
     if (n >= 2 && r >= 1 && r <= 64 && l >= 1 && l <= 64)
       c->tuneRefill = r, c->tuneLeaf = l;
     if (n >= 3 && b >= 1 && b <= 8)
       c->tuneBlocks = b;
     if (n >= 4)
       c->tuneSteal = st ? kFetchShards : 1u;
+    if (n >= 5)
+      c->overlapShadow = ov ? 1u : 0u;
   }
   c->traceBlocks = (uint32_t)c->numCUs * c->tuneBlocks; // 6 blocks x 4 waves = 24 waves per CU: what 24 KB of LDS per block admits
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -1570,6 +1592,9 @@ int rthip_create(int device, rthip_ctx** out)
   HIPCHK(hipEventCreate(&c->evB));
   HIPCHK(hipEventCreate(&c->evK0));
   HIPCHK(hipEventCreate(&c->evK1));
+  HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
   *out = c;
   return 0;
 }
@@ -1585,6 +1610,8 @@ int rthip_destroy(rthip_ctx* c)
   c->anyOut.release(), c->acc.release(), c->img.release(), c->rowScratch.release(), c->aovTri.release(), c->aovShadow.release();
   c->spill.release(), c->fetch.release(), c->listA.release(), c->listB.release(), c->counters.release();
   (void)hipEventDestroy(c->evA), (void)hipEventDestroy(c->evB), (void)hipEventDestroy(c->evK0), (void)hipEventDestroy(c->evK1);
+  (void)hipEventDestroy(c->evFork), (void)hipEventDestroy(c->evJoin);
+  (void)hipStreamDestroy(c->stream2);
   (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
