@@ -285,10 +285,13 @@ def main():
         full_pass_est = cal * 16.0
         if full_pass_est <= args.cpu_seconds:
             passes = int(max(1, min(spp, args.cpu_seconds // max(full_pass_est, 1e-3))))
+            # repeat the sample until about cpu_seconds of CPU work have been timed (a sub-second sample is noisy)
+            reps = int(max(1, min(64, args.cpu_seconds // max(full_pass_est * passes, 1e-3))))
             t1 = time.perf_counter()
-            res = oracle.render(ocam, bw, bh, spp, max_depth=max_depth, samples=(0, passes), workers=CPU_WORKERS, flat=wl["flat_cpu"])
-            cpu_s = time.perf_counter() - t1
-            sample = f"{passes} of {spp} sample passes of the full {bw}x{bh} frame"
+            for _ in range(reps):
+                res = oracle.render(ocam, bw, bh, spp, max_depth=max_depth, samples=(0, passes), workers=CPU_WORKERS, flat=wl["flat_cpu"])
+            cpu_s = (time.perf_counter() - t1) / reps
+            sample = f"{passes} of {spp} sample passes of the full {bw}x{bh} frame, timed {reps}x"
         else:
             cpu_s = cal
             sample = f"1 sample pass of the centre {win[2] - win[0]}x{win[3] - win[1]} window of the {bw}x{bh} frame"

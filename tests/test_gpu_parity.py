@@ -105,6 +105,42 @@ def test_render_matches_oracle_bitexact(name, W, H, N, depth):
     r.close()
 
 
+LIGHT_SETUPS = {
+    # no directional light: no shadow launch exists, the final light fold runs in k_shade
+    "points_only": dict(dir_lights=[], point_lights=[((1.6, 0.4, 0.9), (1, 0.5, 0.25), 3.0), ((0, 2.5, 0), (0.2, 0.9, 0.4), 4.0)]),
+    # three directional lights (one shining upwards from below) and two point lights in range: the fold that the
+    # shadow kernel performs at the last depth must add them in the reference's order
+    "mixed": dict(dir_lights=[(scenes.main_light_dir(), (1, 1, 1)), (np.array([0.6, -0.64, 0.48], np.float32), (0.5, 0.25, 0.125)),
+                              (np.array([0.05, 0.99, 0.13], np.float32), (0.3, 0.3, 0.9))],
+                  point_lights=[((1.6, 0.4, 0.9), (1, 0.5, 0.25), 3.0), ((0, 2.5, 0), (0.2, 0.9, 0.4), 4.0)]),
+    "no_lights": dict(dir_lights=[], point_lights=[]),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("setup", sorted(LIGHT_SETUPS))
+@pytest.mark.parametrize("depth", [1, 2, 7])
+def test_light_configurations_match_oracle_bitexact(setup, depth):
+    base = scenes.multi_model_scene()
+    spec = scenes.SceneSpec("lights_" + setup, base.meshes, base.camera, **LIGHT_SETUPS[setup])
+    W, H, N = 160, 120, 3
+    aov = min(depth, 2)
+    want = spec.build_oracle().render(spec.oracle_camera(), W, H, N, max_depth=depth, aov_depths=aov, workers=14)
+    assert want["counters"]["nonFiniteAccepts"] == 0
+    r = spec.build_product(options=dict(maxDepth=depth, aovDepths=aov))
+    r.begin_frame(spec.product_camera(), W, H, N)
+    for s in range(N):
+        r.render_passes(s, 1)
+        for d in range(aov):
+            tri, sh = r.aov(s, d)
+            assert np.array_equal(tri, want["tri_id"][s, d])
+            if LIGHT_SETUPS[setup]["dir_lights"]:
+                assert np.array_equal(sh, want["shadow"][s, d])
+    assert r.counters()["shadow"] == want["counters"]["shadow"]
+    assert np.array_equal(r.accumulator().view(np.uint32), want["accumulator"].view(np.uint32))
+    r.close()
+
+
 def _render(spec, W, H, N, depth, options=None, tiles=None, passes_per_call=None):
     r = spec.build_product(options=dict(maxDepth=depth, **(options or {})))
     if tiles is not None:
