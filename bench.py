@@ -107,7 +107,7 @@ def main():
     hl = ra.capi.hip_lib()
     ctx = r.context
     n_local_floats = len(assignment[rank]) * ts * ts * 3 if world > 1 else None
-    local_buf = torch.empty((len(assignment[rank]) * ts * ts, 3), dtype=torch.float32, device=f"cuda:{local_rank}") if world > 1 else None
+    local_buf = None
     full_frame = torch.zeros((height, width, 3), dtype=torch.float32, device=f"cuda:{local_rank}") if (world > 1 and rank == 0) else None
     gather_ms = []
 
@@ -123,24 +123,45 @@ def main():
 
     step_rays = np.zeros(4)  # dynamic mode: rays of the current step, summed over its tile batches
 
+    stage = recv = None
+    pending = []
+    if world > 1 and not dynamic:
+        per_rank = rdist.padded_tile_count(assignment) * ts * ts
+        stage = [torch.zeros((per_rank, 3), dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(2)]
+        if rank == 0 and backend == "nccl":
+            recv = [[torch.empty_like(stage[0]) for _ in range(world)] for _ in range(2)]
+
+    def drain():
+        """Completes the gather in flight (if any); rank 0 scatters the tiles it brought into the row-major frame."""
+        while pending:
+            work, dst, _src = pending.pop(0)
+            work.wait()
+            if backend == "nccl":
+                torch.cuda.current_stream().synchronize()
+            if rank == 0:
+                for buf, tiles in zip(dst, assignment):
+                    buf = buf if backend == "nccl" else buf.to(f"cuda:{local_rank}")
+                    rc = hl.rthip_untile(ctx, buf.data_ptr(), ra.capi._up(tiles), len(tiles), full_frame.data_ptr())
+                    assert rc == 0, ra.capi.error_string(rc)
+
     def step():
         if not dynamic:
             r.begin_frame(cam, width, height, spp)
             r.render_passes(0, spp)
         if world > 1 and not dynamic:
+            # The gather of frame k travels while frame k+1 renders: the accumulator is copied into one of two staging
+            # buffers, the collective is started asynchronously, and rank 0 re-tiles a frame one step later (or in drain()).
             t0 = time.perf_counter()
-            rc = hl.rthip_copy_accumulator_to(ctx, local_buf.data_ptr(), n_local_floats)
+            k = frame_no[0] & 1
+            frame_no[0] += 1
+            rc = hl.rthip_copy_accumulator_to(ctx, stage[k].data_ptr(), n_local_floats)
             assert rc == 0, ra.capi.error_string(rc)
-            if backend == "nccl":
-                bufs = rdist.gather_tiles(local_buf, assignment, rank, world, dist)
-            else:
-                bufs = rdist.gather_tiles(local_buf.cpu(), assignment, rank, world, dist)
-                bufs = [b.to(f"cuda:{local_rank}") for b in bufs] if rank == 0 else None
+            drain()
+            src = stage[k] if backend == "nccl" else stage[k].cpu()
+            dst = None
             if rank == 0:
-                for src, tiles in zip(bufs, assignment):
-                    rc = hl.rthip_untile(ctx, src.data_ptr(), ra.capi._up(tiles), len(tiles), full_frame.data_ptr())
-                    assert rc == 0, ra.capi.error_string(rc)
-            torch.cuda.synchronize()
+                dst = recv[k] if backend == "nccl" else [torch.empty_like(src) for _ in range(world)]
+            pending.append((dist.gather(src, dst, dst=0, async_op=True), dst, src))
             gather_ms.append((time.perf_counter() - t0) * 1e3)
         if dynamic:
             # tiles come from the shared cursor in batches; each batch is a frame of its own over just those tiles
@@ -175,6 +196,8 @@ def main():
             gather_ms.append((time.perf_counter() - t0) * 1e3)
 
     def sync_all():
+        drain()
+        hl.rthip_synchronize(ctx)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -219,6 +242,16 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+
+    # ---- the assembled multi-GPU frame must be the single-GPU frame, bit for bit (untimed: rank 0 renders all tiles itself)
+    frame_check = None
+    if world > 1:
+        r.set_tiles(np.arange(tiles_total, dtype=np.uint32))
+        r.begin_frame(cam, width, height, spp)
+        r.render_passes(0, spp)
+        same = np.array_equal(r.accumulator().view(np.uint32), full_frame.cpu().numpy().view(np.uint32))
+        frame_check = "assembled frame bit-identical to a single-GPU render" if same else "MISMATCH against the single-GPU render"
+        r.set_tiles(assignment[rank])
 
     # ---- roofline of the dominant kernel: per-kernel HIP-event timing + algorithmic work counts, in separate untimed frames
     if args.no_roofline:
@@ -310,7 +343,7 @@ def main():
                       "tris": int(flat["info"].numTris), "bvh_nodes": int(flat["info"].numNodes),
                       "rays_per_step": int(rays_frame), "primary": int(t[2]), "secondary_extend": int(t[3]), "shadow": int(t[4]),
                       "parallelism": (f"tiles64-{'dynamic' if dynamic else 'rr'}-x{world}-{backend}" if world > 1 else "single"), "balance": balance,
-                      "gather_ms": round(float(np.mean(gather_ms)), 4) if gather_ms else None},
+                      "gather_ms": round(float(np.mean(gather_ms)), 4) if gather_ms else None, "frame_check": frame_check},
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
     if world > 1:
