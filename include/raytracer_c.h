@@ -24,7 +24,10 @@ typedef struct rt_mesh rt_mesh;
 rt_mesh* rt_mesh_cube(void);                                                   /* stand-in for res/models/cube.fbx */
 rt_mesh* rt_mesh_soup(uint32_t numTriangles, uint64_t seed, float edgeRadius); /* BASELINE.md config 3 */
 rt_mesh* rt_mesh_heightfield(uint32_t quadsPerSide, uint64_t seed, float amplitude); /* BASELINE.md config 4/5 */
-rt_mesh* rt_mesh_load_obj(const char* path);                                   /* NULL on failure */
+rt_mesh* rt_mesh_load_obj(const char* path);                                   /* first model of the file; NULL on failure */
+/* every model of a file (.obj: one; .glb: one per mesh primitive, like the loop over aiScene::mMeshes): returns how many the
+ * file holds and stores up to `capacity` of them in out[] (call with out == NULL to size the array) */
+uint32_t rt_mesh_load_all(const char* path, rt_mesh** out, uint32_t capacity);
 rt_mesh* rt_mesh_from_arrays(const float* positions, uint32_t numPositions, const float* texCoords, const uint32_t* indices,
                              uint32_t numTriangles);
 uint32_t rt_mesh_num_positions(const rt_mesh*);

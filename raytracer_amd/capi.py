@@ -109,6 +109,8 @@ def host_lib():
         L.rt_mesh_soup.argtypes = [C.c_uint32, C.c_uint64, C.c_float]
         L.rt_mesh_heightfield.argtypes = [C.c_uint32, C.c_uint64, C.c_float]
         L.rt_mesh_load_obj.argtypes = [C.c_char_p]
+        L.rt_mesh_load_all.restype = C.c_uint32
+        L.rt_mesh_load_all.argtypes = [C.c_char_p, C.POINTER(vp), C.c_uint32]
         L.rt_mesh_from_arrays.argtypes = [fp, C.c_uint32, fp, up, C.c_uint32]
         L.rt_mesh_num_positions.restype = C.c_uint32
         L.rt_mesh_num_positions.argtypes = [vp]
@@ -187,6 +189,16 @@ class Mesh:
     @classmethod
     def load_obj(cls, path):
         return cls(host_lib().rt_mesh_load_obj(os.fsencode(path)))
+
+    @classmethod
+    def load_all(cls, path):
+        """Every model of a file (.obj, .glb), in file order -- what ModelLoader::loadModel returns."""
+        n = host_lib().rt_mesh_load_all(os.fsencode(path), None, 0)
+        if n == 0:
+            raise RtError(RTHIP_E_ARG, "no model could be read from %s" % path)
+        arr = (C.c_void_p * n)()
+        host_lib().rt_mesh_load_all(os.fsencode(path), arr, n)
+        return [cls(h) for h in arr]
 
     @classmethod
     def from_arrays(cls, positions, indices):

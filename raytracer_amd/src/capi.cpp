@@ -64,6 +64,16 @@ rt_mesh* rt_mesh_load_obj(const char* path)
     return nullptr;
   return wrap(std::move(models[0]));
 }
+uint32_t rt_mesh_load_all(const char* path, rt_mesh** out, uint32_t capacity)
+{
+  if (!path)
+    return 0;
+  std::vector<PModel> models = ModelLoader::loadModel(path);
+  const uint32_t n = (uint32_t)models.size();
+  for (uint32_t k = 0; out && k < n && k < capacity; ++k)
+    out[k] = wrap(std::move(models[k]));
+  return n;
+}
 rt_mesh* rt_mesh_from_arrays(const float* positions, uint32_t numPositions, const float* texCoords, const uint32_t* indices,
                              uint32_t numTriangles)
 {

@@ -2,14 +2,19 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <cctype>
+#include <cstddef>
 #include <string>
+#include <utility>
 
 namespace rt
 {
-std::vector<PModel> ModelLoader::loadModel(std::string_view filename)
+namespace
+{
+std::vector<PModel> loadObj(const std::string& path)
 {
   std::vector<PModel> result;
-  const std::string path(filename);
   std::FILE* f = std::fopen(path.c_str(), "rb");
   if (!f)
   {
@@ -68,5 +73,326 @@ std::vector<PModel> ModelLoader::loadModel(std::string_view filename)
   if (!model->indices.empty())
     result.push_back(std::move(model));
   return result;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Binary glTF 2.0 (.glb: res/models/box.glb, town_hall.glb).  Like the reference's loop over aiScene::mMeshes
+// (ModelLoader.cpp:14-41) this returns one Model per mesh primitive, in file order, with the vertices exactly as stored
+// (POSITION accessor order) and NO node transform applied -- the reference never looks at the node hierarchy.  Only what
+// that loop reads is decoded: positions, triangle indices, the first texture-coordinate set.
+struct Json
+{
+  enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
+  double number = 0.0;
+  bool boolean = false;
+  std::string string;
+  std::vector<Json> items;                          // Array
+  std::vector<std::pair<std::string, Json>> fields; // Object
+  const Json* get(const char* key) const
+  {
+    for (const auto& f : fields)
+      if (f.first == key)
+        return &f.second;
+    return nullptr;
+  }
+  long integer(const char* key, long fallback) const
+  {
+    const Json* j = get(key);
+    return (j && j->kind == Number) ? (long)j->number : fallback;
+  }
+};
+
+struct JsonParser
+{
+  const char* p;
+  const char* end;
+  bool ok = true;
+  void skip()
+  {
+    while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r'))
+      ++p;
+  }
+  bool eat(char c)
+  {
+    skip();
+    if (p < end && *p == c)
+    {
+      ++p;
+      return true;
+    }
+    return false;
+  }
+  std::string parseString()
+  {
+    std::string out;
+    if (!eat('"'))
+    {
+      ok = false;
+      return out;
+    }
+    while (p < end && *p != '"')
+    {
+      if (*p == '\\' && p + 1 < end)
+      {
+        ++p;
+        switch (*p)
+        {
+        case 'n': out.push_back('\n'); break;
+        case 't': out.push_back('\t'); break;
+        case 'u': p += (end - p > 4) ? 4 : 0; out.push_back('?'); break; // names are never needed as text here
+        default: out.push_back(*p); break;
+        }
+        ++p;
+      }
+      else
+        out.push_back(*p++);
+    }
+    if (p >= end)
+      ok = false;
+    else
+      ++p;
+    return out;
+  }
+  Json parse(int depth = 0)
+  {
+    Json j;
+    skip();
+    if (!ok || p >= end || depth > 64)
+    {
+      ok = false;
+      return j;
+    }
+    if (*p == '{')
+    {
+      ++p;
+      j.kind = Json::Object;
+      if (eat('}'))
+        return j;
+      do
+      {
+        std::string key = parseString();
+        if (!ok || !eat(':'))
+        {
+          ok = false;
+          return j;
+        }
+        j.fields.emplace_back(std::move(key), parse(depth + 1));
+      } while (ok && eat(','));
+      if (!eat('}'))
+        ok = false;
+    }
+    else if (*p == '[')
+    {
+      ++p;
+      j.kind = Json::Array;
+      if (eat(']'))
+        return j;
+      do
+        j.items.push_back(parse(depth + 1));
+      while (ok && eat(','));
+      if (!eat(']'))
+        ok = false;
+    }
+    else if (*p == '"')
+    {
+      j.kind = Json::String;
+      j.string = parseString();
+    }
+    else if (end - p >= 4 && std::strncmp(p, "true", 4) == 0)
+      j.kind = Json::Bool, j.boolean = true, p += 4;
+    else if (end - p >= 5 && std::strncmp(p, "false", 5) == 0)
+      j.kind = Json::Bool, p += 5;
+    else if (end - p >= 4 && std::strncmp(p, "null", 4) == 0)
+      p += 4;
+    else
+    {
+      const std::string text(p, (size_t)std::min<ptrdiff_t>(end - p, 63));
+      char* stop = nullptr;
+      j.number = std::strtod(text.c_str(), &stop);
+      if (stop == text.c_str())
+        ok = false;
+      else
+        j.kind = Json::Number, p += stop - text.c_str();
+    }
+    return j;
+  }
+};
+
+uint32_t readU32(const unsigned char* b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); }
+
+// a typed view of one accessor over the GLB's binary chunk; count == 0 when it cannot be used
+struct AccessorView
+{
+  const unsigned char* base = nullptr;
+  size_t stride = 0, count = 0;
+  long componentType = 0;
+  int components = 0;
+};
+
+AccessorView viewAccessor(const Json& root, long index, const std::vector<unsigned char>& bin)
+{
+  AccessorView v;
+  const Json* accessors = root.get("accessors");
+  const Json* views = root.get("bufferViews");
+  if (!accessors || !views || index < 0 || (size_t)index >= accessors->items.size())
+    return v;
+  const Json& acc = accessors->items[(size_t)index];
+  if (acc.get("sparse"))
+    return v; // not produced by the exporters behind res/models; refused rather than mis-read
+  const long bv = acc.integer("bufferView", -1);
+  if (bv < 0 || (size_t)bv >= views->items.size())
+    return v;
+  const Json& view = views->items[(size_t)bv];
+  if (view.integer("buffer", 0) != 0)
+    return v; // a .glb keeps everything in buffer 0, the BIN chunk
+  const Json* type = acc.get("type");
+  const std::string t = type ? type->string : "";
+  v.components = t == "SCALAR" ? 1 : t == "VEC2" ? 2 : t == "VEC3" ? 3 : t == "VEC4" ? 4 : 0;
+  v.componentType = acc.integer("componentType", 0);
+  const size_t compBytes = (v.componentType == 5120 || v.componentType == 5121)   ? 1
+                           : (v.componentType == 5122 || v.componentType == 5123) ? 2
+                           : (v.componentType == 5125 || v.componentType == 5126) ? 4
+                                                                                  : 0;
+  if (!v.components || !compBytes)
+    return v;
+  const size_t elem = compBytes * (size_t)v.components;
+  const size_t offset = (size_t)view.integer("byteOffset", 0) + (size_t)acc.integer("byteOffset", 0);
+  const long strideField = view.integer("byteStride", 0);
+  v.stride = strideField > 0 ? (size_t)strideField : elem;
+  const size_t count = (size_t)acc.integer("count", 0);
+  if (count == 0 || v.stride < elem || offset > bin.size() || (count - 1) * v.stride + elem > bin.size() - offset)
+    return v;
+  v.base = bin.data() + offset;
+  v.count = count;
+  return v;
+}
+
+std::vector<PModel> loadGlb(const std::string& path)
+{
+  std::vector<PModel> result;
+  std::FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f)
+  {
+    std::fprintf(stderr, "ModelLoader: cannot open %s\n", path.c_str());
+    return result;
+  }
+  std::vector<unsigned char> file;
+  unsigned char buf[65536];
+  size_t got;
+  while ((got = std::fread(buf, 1, sizeof(buf), f)) > 0)
+    file.insert(file.end(), buf, buf + got);
+  std::fclose(f);
+  if (file.size() < 20 || readU32(file.data()) != 0x46546C67u /* "glTF" */ || readU32(file.data() + 4) != 2u)
+  {
+    std::fprintf(stderr, "ModelLoader: %s is not a binary glTF 2.0 file\n", path.c_str());
+    return result;
+  }
+  std::string jsonText;
+  std::vector<unsigned char> bin;
+  size_t at = 12;
+  const size_t total = std::min<size_t>(file.size(), readU32(file.data() + 8));
+  while (at + 8 <= total)
+  {
+    const size_t len = readU32(file.data() + at);
+    const uint32_t type = readU32(file.data() + at + 4);
+    at += 8;
+    if (len > total - at)
+      break;
+    if (type == 0x4E4F534Au /* JSON */ && jsonText.empty())
+      jsonText.assign((const char*)file.data() + at, len);
+    else if (type == 0x004E4942u /* BIN */ && bin.empty())
+      bin.assign(file.begin() + (ptrdiff_t)at, file.begin() + (ptrdiff_t)(at + len));
+    at += (len + 3u) & ~(size_t)3u;
+  }
+  JsonParser parser{jsonText.data(), jsonText.data() + jsonText.size()};
+  const Json root = parser.parse();
+  const Json* meshes = root.get("meshes");
+  if (!parser.ok || root.kind != Json::Object || !meshes)
+  {
+    std::fprintf(stderr, "ModelLoader: %s: malformed glTF JSON\n", path.c_str());
+    return result;
+  }
+  for (const Json& mesh : meshes->items)
+  {
+    const Json* prims = mesh.get("primitives");
+    if (!prims)
+      continue;
+    for (const Json& prim : prims->items)
+    {
+      if (prim.integer("mode", 4) != 4)
+        continue; // triangles only: points and lines have no faces for aiProcess_Triangulate to keep either
+      const Json* attrs = prim.get("attributes");
+      if (!attrs)
+        continue;
+      const AccessorView pos = viewAccessor(root, attrs->integer("POSITION", -1), bin);
+      if (!pos.count || pos.componentType != 5126 || pos.components != 3)
+        continue;
+      auto model = std::make_unique<Model>();
+      model->positions.resize(pos.count);
+      for (size_t v = 0; v < pos.count; ++v)
+      {
+        float xyz[3];
+        std::memcpy(xyz, pos.base + v * pos.stride, 12);
+        model->positions[v] = vec3{xyz[0], xyz[1], xyz[2]};
+        model->boundingBox.adjust(model->positions[v]);
+      }
+      model->texCoords.assign(pos.count, vec2{0.0f, 0.0f});
+      const AccessorView uv = viewAccessor(root, attrs->integer("TEXCOORD_0", -1), bin);
+      if (uv.count == pos.count && uv.componentType == 5126 && uv.components == 2)
+        for (size_t v = 0; v < pos.count; ++v)
+        {
+          float st[2];
+          std::memcpy(st, uv.base + v * uv.stride, 8);
+          model->texCoords[v] = vec2{st[0], st[1]};
+        }
+      model->normals.assign(pos.count, vec3{0.0f, 0.0f, 0.0f}); // never read on the hot path (face normals are recomputed)
+      std::vector<uint32_t> idx;
+      const long indexAccessor = prim.integer("indices", -1);
+      if (indexAccessor >= 0)
+      {
+        const AccessorView iv = viewAccessor(root, indexAccessor, bin);
+        if (!iv.count || iv.components != 1)
+          continue;
+        idx.resize(iv.count);
+        for (size_t k = 0; k < iv.count; ++k)
+        {
+          const unsigned char* e = iv.base + k * iv.stride;
+          idx[k] = iv.componentType == 5121 ? e[0] : iv.componentType == 5123 ? (uint32_t)(e[0] | (e[1] << 8)) : iv.componentType == 5125 ? readU32(e) : 0xffffffffu;
+        }
+      }
+      else
+      {
+        idx.resize(pos.count);
+        for (size_t k = 0; k < pos.count; ++k)
+          idx[k] = (uint32_t)k;
+      }
+      for (size_t k = 0; k + 2 < idx.size(); k += 3)
+        if (idx[k] < pos.count && idx[k + 1] < pos.count && idx[k + 2] < pos.count)
+          model->indices.push_back(uvec3{idx[k], idx[k + 1], idx[k + 2]});
+      if (!model->indices.empty())
+        result.push_back(std::move(model));
+    }
+  }
+  return result;
+}
+
+bool endsWith(const std::string& s, const char* suffix)
+{
+  const size_t n = std::strlen(suffix);
+  if (s.size() < n)
+    return false;
+  for (size_t k = 0; k < n; ++k)
+    if (std::tolower((unsigned char)s[s.size() - n + k]) != suffix[k])
+      return false;
+  return true;
+}
+} // namespace
+
+std::vector<PModel> ModelLoader::loadModel(std::string_view filename)
+{
+  const std::string path(filename);
+  if (endsWith(path, ".glb"))
+    return loadGlb(path);
+  return loadObj(path);
 }
 } // namespace rt

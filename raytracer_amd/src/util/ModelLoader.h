@@ -1,7 +1,9 @@
 // ModelLoader.h -- file loading behind the reference's entry point ModelLoader::loadModel
 // (src/util/ModelLoader.h, ModelLoader.cpp:8-43).  The reference delegates to assimp, which is not available
 // here; this loader reads Wavefront OBJ (v / f records, polygons fan-triangulated like aiProcess_Triangulate does
-// for convex faces), enough for res/models/stanford-bunny.obj.  One Model per file.
+// for convex faces; one Model per file: res/models/stanford-bunny.obj) and binary glTF 2.0 (.glb; one Model per mesh
+// primitive in file order, node transforms ignored as the reference ignores them: res/models/box.glb, town_hall.glb).
+// Binary FBX (cube.fbx, box.fbx) is not read; the procedural cube stands in for cube.fbx.
 #pragma once
 #include "util/Model.h"
 #include <string_view>

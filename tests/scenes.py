@@ -106,3 +106,23 @@ def multi_model_scene():
               (ra.Mesh.cube(), translate(1.4, 0.3, -0.2) @ scale(0.5)),
               (ra.Mesh.heightfield(8, 3, 0.3), translate(0, -1.2, 0))]
     return SceneSpec("multi", meshes, dict(position=(1.0, 2.0, 6.0), target=(0, 0, 0), S_O=6, f=0, A=0))
+
+
+def glb_meshes(name):
+    """Meshes of the reference's res/models/<name>.glb (fixture: tests/golden/glb_meshes.npz, one per mesh primitive)."""
+    z = np.load(os.path.join(GOLDEN, "glb_meshes.npz"))
+    return [ra.Mesh.from_arrays(z["%s_%d_positions" % (name, k)], z["%s_%d_indices" % (name, k)]) for k in range(int(z[name + "_count"]))]
+
+
+def box_glb_scene():
+    """res/models/box.glb as ModelLoader::loadModel + addModel(identity) would set it up: a cube inside five wall quads at
+    +-10, every mesh a model of its own.  Two walls are exactly flat (invisible to the reference's strict slab test), three
+    are 2e-6 thick."""
+    return SceneSpec("box_glb", [(m, ra.capi.IDENTITY) for m in glb_meshes("box")], MAIN_CAMERA)
+
+
+def town_hall_scene():
+    """res/models/town_hall.glb (two meshes, 58 triangles)."""
+    return SceneSpec("town_hall", [(m, ra.capi.IDENTITY) for m in glb_meshes("town_hall")],
+                     dict(position=(16.0, 7.0, 15.0), target=(2.5, 2.0, 0.0), S_O=6, f=0, A=0),
+                     point_lights=[((2.0, 2.0, 0.0), (1.0, 0.8, 0.6), 12.0)])

@@ -67,10 +67,11 @@ def test_probe_bounce_bitexact(probe):
 
 
 @pytest.mark.parametrize("name,W,H,N,depth", [("cube", 256, 192, 4, 12), ("cube", 250, 130, 2, 1), ("bunny", 160, 160, 2, 4),
-                                             ("soup", 200, 200, 2, 6), ("hf", 192, 128, 2, 5), ("multi", 192, 160, 2, 6)])
+                                             ("soup", 200, 200, 2, 6), ("hf", 192, 128, 2, 5), ("multi", 192, 160, 2, 6),
+                                             ("box_glb", 200, 150, 3, 8), ("town_hall", 200, 150, 3, 8)])
 def test_render_matches_oracle_bitexact(name, W, H, N, depth):
     spec = {"cube": scenes.cube_scene, "bunny": scenes.bunny_scene, "soup": scenes.soup_scene, "hf": scenes.heightfield_scene,
-            "multi": scenes.multi_model_scene}[name]()
+            "multi": scenes.multi_model_scene, "box_glb": scenes.box_glb_scene, "town_hall": scenes.town_hall_scene}[name]()
     aov = min(depth, 3)
     oracle = spec.build_oracle()
     want = oracle.render(spec.oracle_camera(), W, H, N, max_depth=depth, aov_depths=aov, workers=14)
