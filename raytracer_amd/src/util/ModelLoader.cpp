@@ -7,6 +7,7 @@
 #include <cstddef>
 #include <string>
 #include <utility>
+#include <zlib.h>
 
 namespace rt
 {
@@ -376,6 +377,222 @@ std::vector<PModel> loadGlb(const std::string& path)
   return result;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Binary FBX 7.x (res/models/cube.fbx, box.fbx).  Only what the reference's loop over aiScene::mMeshes reads is decoded:
+// for every Objects/Geometry node the control points (`Vertices`, doubles) and the polygon list (`PolygonVertexIndex`, the
+// last corner of a polygon stored as ~index).  The result mimics what assimp's FBX importer + aiProcess_Triangulate hand
+// the reference: one vertex PER POLYGON CORNER in polygon order (no sharing), polygons fan-triangulated from their first
+// corner, no node transform, no unit scaling.  (assimp is absent, so that it emits exactly this order is an assumption
+// read off its documented behaviour -- "parity unpinned" for ingestion.)
+struct FbxArray
+{
+  char type = 0;
+  std::vector<unsigned char> raw; // decoded little-endian elements
+  size_t count = 0;
+};
+
+struct FbxReader
+{
+  const std::vector<unsigned char>& d;
+  bool wide; // version >= 7500: 64-bit node header fields
+  bool ok = true;
+  std::vector<PModel>* out;
+
+  uint64_t field(size_t& at)
+  {
+    const size_t n = wide ? 8 : 4;
+    if (at + n > d.size())
+    {
+      ok = false;
+      return 0;
+    }
+    uint64_t v = 0;
+    for (size_t k = 0; k < n; ++k)
+      v |= (uint64_t)d[at + k] << (8 * k);
+    at += n;
+    return v;
+  }
+  // reads one property at `at`; fills `arr` when it is an array property
+  void property(size_t& at, FbxArray* arr)
+  {
+    if (at >= d.size())
+    {
+      ok = false;
+      return;
+    }
+    const char t = (char)d[at++];
+    size_t scalar = 0;
+    switch (t)
+    {
+    case 'Y': scalar = 2; break;
+    case 'C': scalar = 1; break;
+    case 'I': case 'F': scalar = 4; break;
+    case 'D': case 'L': scalar = 8; break;
+    default: break;
+    }
+    if (scalar)
+    {
+      at += scalar;
+      return;
+    }
+    if (t == 'S' || t == 'R')
+    {
+      if (at + 4 > d.size())
+      {
+        ok = false;
+        return;
+      }
+      at += 4 + readU32(d.data() + at);
+      return;
+    }
+    const size_t elem = (t == 'f' || t == 'i') ? 4 : (t == 'd' || t == 'l') ? 8 : (t == 'b') ? 1 : 0;
+    if (!elem || at + 12 > d.size())
+    {
+      ok = false;
+      return;
+    }
+    const size_t count = readU32(d.data() + at), encoding = readU32(d.data() + at + 4), stored = readU32(d.data() + at + 8);
+    at += 12;
+    if (stored > d.size() - at)
+    {
+      ok = false;
+      return;
+    }
+    if (arr)
+    {
+      arr->type = t;
+      arr->count = count;
+      arr->raw.resize(count * elem);
+      if (encoding == 0)
+      {
+        if (stored != count * elem)
+          ok = false;
+        else
+          std::memcpy(arr->raw.data(), d.data() + at, stored);
+      }
+      else
+      {
+        uLongf got = (uLongf)arr->raw.size();
+        if (uncompress(arr->raw.data(), &got, d.data() + at, (uLong)stored) != Z_OK || got != arr->raw.size())
+          ok = false;
+      }
+    }
+    at += stored;
+  }
+  // walks the node at `at`; returns the offset after it (0 at a null record or on error)
+  size_t node(size_t at, int depth, FbxArray* vertices, FbxArray* polygons)
+  {
+    const size_t start = at;
+    const uint64_t end = field(at), numProps = field(at), propBytes = field(at);
+    (void)propBytes;
+    if (!ok || at >= d.size())
+      return 0;
+    const size_t nameLen = d[at++];
+    if (end == 0)
+      return 0; // null record: end of a child list
+    if (end > d.size() || end <= start || at + nameLen > d.size() || depth > 32)
+    {
+      ok = false;
+      return 0;
+    }
+    const std::string name((const char*)d.data() + at, nameLen);
+    at += nameLen;
+    const bool isVertices = vertices && name == "Vertices", isPolygons = polygons && name == "PolygonVertexIndex";
+    for (uint64_t k = 0; ok && k < numProps; ++k)
+      property(at, (k == 0 && isVertices) ? vertices : (k == 0 && isPolygons) ? polygons : nullptr);
+    if (!ok)
+      return 0;
+    FbxArray geoVertices, geoPolygons;
+    const bool isGeometry = name == "Geometry";
+    while (ok && at + (wide ? 25u : 13u) <= end)
+    {
+      const size_t next = node(at, depth + 1, isGeometry ? &geoVertices : vertices, isGeometry ? &geoPolygons : polygons);
+      if (!next)
+        break;
+      at = next;
+    }
+    if (ok && isGeometry)
+      emit(geoVertices, geoPolygons);
+    return ok ? (size_t)end : 0;
+  }
+  void emit(const FbxArray& v, const FbxArray& p)
+  {
+    if (v.type != 'd' || p.type != 'i' || v.count < 9 || p.count < 3)
+      return; // not a mesh geometry (e.g. a shape or a line)
+    const size_t numPoints = v.count / 3;
+    auto model = std::make_unique<Model>();
+    std::vector<uint32_t> polygon;
+    for (size_t k = 0; k < p.count; ++k)
+    {
+      int32_t raw;
+      std::memcpy(&raw, p.raw.data() + 4 * k, 4);
+      const bool last = raw < 0;
+      const uint32_t point = (uint32_t)(last ? ~raw : raw);
+      if (point >= numPoints)
+      {
+        polygon.clear();
+        if (!last)
+          continue;
+      }
+      else
+      {
+        double xyz[3];
+        std::memcpy(xyz, v.raw.data() + 24 * (size_t)point, 24);
+        polygon.push_back((uint32_t)model->positions.size());
+        model->positions.push_back(vec3{(float)xyz[0], (float)xyz[1], (float)xyz[2]}); // one vertex per polygon corner
+        model->boundingBox.adjust(model->positions.back());
+      }
+      if (last)
+      {
+        for (size_t c = 2; c < polygon.size(); ++c) // (0,1,2), (0,2,3), ...: aiProcess_Triangulate on convex polygons
+          model->indices.push_back(uvec3{polygon[0], polygon[c - 1], polygon[c]});
+        polygon.clear();
+      }
+    }
+    model->texCoords.assign(model->positions.size(), vec2{0.0f, 0.0f});
+    model->normals.assign(model->positions.size(), vec3{0.0f, 0.0f, 0.0f});
+    if (!model->indices.empty())
+      out->push_back(std::move(model));
+  }
+};
+
+std::vector<PModel> loadFbx(const std::string& path)
+{
+  std::vector<PModel> result;
+  std::FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f)
+  {
+    std::fprintf(stderr, "ModelLoader: cannot open %s\n", path.c_str());
+    return result;
+  }
+  std::vector<unsigned char> file;
+  unsigned char buf[65536];
+  size_t got;
+  while ((got = std::fread(buf, 1, sizeof(buf), f)) > 0)
+    file.insert(file.end(), buf, buf + got);
+  std::fclose(f);
+  if (file.size() < 27 || std::memcmp(file.data(), "Kaydara FBX Binary  ", 20) != 0)
+  {
+    std::fprintf(stderr, "ModelLoader: %s is not a binary FBX file (ASCII FBX is not read)\n", path.c_str());
+    return result;
+  }
+  FbxReader reader{file, readU32(file.data() + 23) >= 7500u, true, &result};
+  size_t at = 27;
+  while (reader.ok && at + (reader.wide ? 25u : 13u) <= file.size())
+  {
+    const size_t next = reader.node(at, 0, nullptr, nullptr);
+    if (!next)
+      break;
+    at = next;
+  }
+  if (!reader.ok)
+  {
+    std::fprintf(stderr, "ModelLoader: %s: malformed FBX node list\n", path.c_str());
+    result.clear();
+  }
+  return result;
+}
+
 bool endsWith(const std::string& s, const char* suffix)
 {
   const size_t n = std::strlen(suffix);
@@ -393,6 +610,8 @@ std::vector<PModel> ModelLoader::loadModel(std::string_view filename)
   const std::string path(filename);
   if (endsWith(path, ".glb"))
     return loadGlb(path);
+  if (endsWith(path, ".fbx"))
+    return loadFbx(path);
   return loadObj(path);
 }
 } // namespace rt

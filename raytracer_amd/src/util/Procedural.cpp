@@ -28,17 +28,18 @@ static void finishModel(Model& m)
 
 PModel makeCube()
 {
+  // The geometry of res/models/cube.fbx as data: its 8 control points and 6 quads (Objects/Geometry: Vertices,
+  // PolygonVertexIndex), expanded the way ModelLoader expands a binary FBX -- one vertex per polygon corner in polygon
+  // order, each quad split (0,1,2), (0,2,3) -- so triangle ids match a load of the file itself
+  // (tests/test_model_loader_cpu.py compares the two where the file exists).  All windings face outward.
   auto m = std::make_unique<Model>();
-  // face normal n and two in-face axes u, v with u x v = n
-  const int faces[6][3][3] = {{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}},  {{-1, 0, 0}, {0, 0, 1}, {0, 1, 0}}, {{0, 1, 0}, {0, 0, 1}, {1, 0, 0}},
-                              {{0, -1, 0}, {1, 0, 0}, {0, 0, 1}}, {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}},  {{0, 0, -1}, {0, 1, 0}, {1, 0, 0}}};
-  const int corner[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
-  for (const auto& f : faces)
+  const float points[8][3] = {{1, 1, -1}, {1, -1, -1}, {1, 1, 1}, {1, -1, 1}, {-1, 1, -1}, {-1, -1, -1}, {-1, 1, 1}, {-1, -1, 1}};
+  const int quads[6][4] = {{0, 4, 6, 2}, {3, 2, 6, 7}, {7, 6, 4, 5}, {5, 1, 3, 7}, {1, 0, 2, 3}, {5, 4, 0, 1}};
+  for (const auto& q : quads)
   {
     const uint32_t base = (uint32_t)m->positions.size();
-    for (const auto& c : corner)
-      m->positions.push_back(vec3{(float)(f[0][0] + c[0] * f[1][0] + c[1] * f[2][0]), (float)(f[0][1] + c[0] * f[1][1] + c[1] * f[2][1]),
-                                  (float)(f[0][2] + c[0] * f[1][2] + c[1] * f[2][2])});
+    for (int c : q)
+      m->positions.push_back(vec3{points[c][0], points[c][1], points[c][2]});
     m->indices.push_back(uvec3{base, base + 1, base + 2});
     m->indices.push_back(uvec3{base, base + 2, base + 3});
   }

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import raytracer_amd as ra
-from tests import glb_util
+from tests import fbx_util, glb_util
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 REF_MODELS = "/root/reference/res/models"
@@ -74,3 +74,47 @@ def test_shipped_obj_matches_fixture():
     p, i = ra.Mesh.load_all(os.path.join(REF_MODELS, "stanford-bunny.obj"))[0].arrays()
     z = np.load(os.path.join(GOLDEN, "bunny_mesh.npz"))
     assert np.array_equal(p, z["positions"]) and np.array_equal(i, z["indices"])
+
+
+@pytest.mark.parametrize("version,compress", [(7400, False), (7400, True), (7500, True)])
+def test_synthetic_fbx_round_trip(tmp_path, version, compress):
+    rng = np.random.default_rng(9)
+    geos = []
+    for k in range(3):
+        pts = rng.normal(size=(12 + 5 * k, 3))
+        polys = [rng.choice(len(pts), size=n, replace=False).tolist() for n in (3, 4, 4, 5, 3, 6)]
+        geos.append((pts, polys))
+    data = fbx_util.write_fbx(geos, version=version, compress=compress)
+    path = tmp_path / "synthetic.fbx"
+    path.write_bytes(data)
+    want = fbx_util.parse_fbx(data)
+    assert len(want) == 3 and want[0][1].shape == (1 + 2 + 2 + 3 + 1 + 4, 3) and want[0][0].shape == (25, 3)
+    _check(ra.Mesh.load_all(str(path)), want)
+
+
+def test_broken_fbx_files_are_refused(tmp_path):
+    good = fbx_util.write_fbx([(np.eye(3), [[0, 1, 2]])])
+    for name, data in [("truncated.fbx", good[: len(good) - 40]), ("ascii.fbx", b"; FBX 7.4.0 project file\n"), ("empty.fbx", b"")]:
+        p = tmp_path / name
+        p.write_bytes(data)
+        with pytest.raises(ra.capi.RtError):
+            ra.Mesh.load_all(str(p))
+
+
+def test_procedural_cube_is_cube_fbx_as_data():
+    """Mesh.cube() carries cube.fbx's 8 control points and 6 quads; expanded per polygon corner it must equal what the FBX
+    reader makes of the same data."""
+    points = [(1, 1, -1), (1, -1, -1), (1, 1, 1), (1, -1, 1), (-1, 1, -1), (-1, -1, -1), (-1, 1, 1), (-1, -1, 1)]
+    quads = [[0, 4, 6, 2], [3, 2, 6, 7], [7, 6, 4, 5], [5, 1, 3, 7], [1, 0, 2, 3], [5, 4, 0, 1]]
+    want = fbx_util.parse_fbx(fbx_util.write_fbx([(np.array(points, np.float64), quads)]))
+    _check([ra.Mesh.cube()], want)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_MODELS), reason="the reference's res/models only exists in the build container")
+def test_shipped_fbx_models():
+    cube = ra.Mesh.load_all(os.path.join(REF_MODELS, "cube.fbx"))
+    _check(cube, fbx_util.parse_fbx(open(os.path.join(REF_MODELS, "cube.fbx"), "rb").read()))
+    _check([ra.Mesh.cube()], [cube[0].arrays()])  # the procedural stand-in IS the file's geometry
+    box = ra.Mesh.load_all(os.path.join(REF_MODELS, "box.fbx"))
+    _check(box, fbx_util.parse_fbx(open(os.path.join(REF_MODELS, "box.fbx"), "rb").read()))
+    assert [(m.num_positions, m.num_triangles) for m in box] == [(28, 14)] + [(4, 2)] * 5
