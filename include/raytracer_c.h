@@ -61,6 +61,10 @@ int rt_render_passes(rt_renderer*, uint32_t begin, uint32_t count, float* msOut)
 uint32_t rt_get_sample_times(rt_renderer*, float* msOut, uint32_t cap);        /* ::getSampleTimes */
 int rt_read_accumulator(rt_renderer*, float* rgbOut);                          /* CPURenderer::accumulator */
 int rt_read_image(rt_renderer*, float* rgbOut);                                /* CPURenderer::image */
+/* headless stand-in for the reference's window (CPURenderer.cpp:118-136 uploads `image` to a GL texture every frame): the
+ * tonemapped image of the current frame as a binary PPM (P6, 8 bits per channel, values clamped to [0,1]) */
+int rt_save_image(rt_renderer*, const char* path, uint32_t width, uint32_t height);
+int rt_write_ppm(const char* path, const float* rgb, uint32_t width, uint32_t height); /* the encoder alone (any row-major RGB floats) */
 int rt_read_aov(rt_renderer*, uint32_t samp, uint32_t depth, uint32_t* triIdOut, uint8_t* shadowOut);
 int rt_get_counters(rt_renderer*, rthip_counters* out);
 int rt_get_kernel_times(rt_renderer*, float msOut[6], uint32_t launchesOut[6]);

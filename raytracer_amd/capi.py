@@ -135,6 +135,8 @@ def host_lib():
         L.rt_get_sample_times.argtypes = [vp, fp, C.c_uint32]
         L.rt_read_accumulator.argtypes = [vp, fp]
         L.rt_read_image.argtypes = [vp, fp]
+        L.rt_save_image.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_uint32]
+        L.rt_write_ppm.argtypes = [C.c_char_p, fp, C.c_uint32, C.c_uint32]
         L.rt_read_aov.argtypes = [vp, C.c_uint32, C.c_uint32, up, C.POINTER(C.c_uint8)]
         L.rt_get_counters.argtypes = [vp, C.POINTER(Counters)]
         L.rt_get_kernel_times.argtypes = [vp, fp, up]
@@ -310,6 +312,11 @@ class Renderer:
         _check(host_lib().rt_read_accumulator(self._h, _fp(out)), "rt_read_accumulator")
         return out
 
+    def save_image(self, path):
+        """Writes the tonemapped image of the current frame as a binary PPM."""
+        h, w = self._size
+        _check(host_lib().rt_save_image(self._h, os.fsencode(path), w, h), "rt_save_image")
+
     def image(self):
         h, w = self._size
         out = np.zeros((h, w, 3), np.float32)
@@ -397,3 +404,9 @@ class Probe:
         _check(hip_lib().rthip_probe_trace(self.ctx, _fp(o), _fp(d), n, float(np.float32(tmin)), float(np.float32(tmax)), _up(tri), _fp(t),
                                            anyh.ctypes.data_as(C.POINTER(C.c_uint8))), "rthip_probe_trace")
         return tri, t, anyh
+
+
+def write_ppm(path, rgb):
+    """Row-major (H, W, 3) floats in [0, 1] -> binary PPM (the encoder behind Renderer.save_image)."""
+    a = np.ascontiguousarray(rgb, np.float32)
+    _check(host_lib().rt_write_ppm(os.fsencode(path), _fp(a), a.shape[1], a.shape[0]), "rt_write_ppm")

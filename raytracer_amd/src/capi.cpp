@@ -1,4 +1,5 @@
 // capi.cpp -- the C ABI of include/raytracer_c.h over the C++ Renderer interface.
+#include <cstdio>
 #include "raytracer_c.h"
 
 #include "hip/HIPRenderer.h"
@@ -262,6 +263,38 @@ uint32_t rt_get_sample_times(rt_renderer* r, float* msOut, uint32_t cap)
 }
 int rt_read_accumulator(rt_renderer* r, float* rgb) { return r ? r->hip->readAccumulator(rgb) : RTHIP_E_ARG; }
 int rt_read_image(rt_renderer* r, float* rgb) { return r ? r->hip->readImage(rgb) : RTHIP_E_ARG; }
+int rt_write_ppm(const char* path, const float* rgb, uint32_t width, uint32_t height)
+{
+  if (!path || !rgb || !width || !height)
+    return RTHIP_E_ARG;
+  std::FILE* f = std::fopen(path, "wb");
+  if (!f)
+    return RTHIP_E_ARG;
+  std::fprintf(f, "P6\n%u %u\n255\n", width, height);
+  std::vector<unsigned char> row((size_t)width * 3);
+  for (uint32_t y = 0; y < height; ++y)
+  {
+    for (size_t k = 0; k < row.size(); ++k)
+    {
+      const float v = rgb[(size_t)y * row.size() + k];
+      row[k] = (unsigned char)(v >= 1.0f ? 255 : v > 0.0f ? (int)(v * 255.0f + 0.5f) : 0); // NaN -> 0
+    }
+    if (std::fwrite(row.data(), 1, row.size(), f) != row.size())
+    {
+      std::fclose(f);
+      return RTHIP_E_ARG;
+    }
+  }
+  return std::fclose(f) == 0 ? 0 : RTHIP_E_ARG;
+}
+int rt_save_image(rt_renderer* r, const char* path, uint32_t width, uint32_t height)
+{
+  if (!r || !path || !width || !height)
+    return RTHIP_E_ARG;
+  std::vector<float> rgb((size_t)width * height * 3, 0.0f);
+  const int rc = r->hip->readImage(rgb.data());
+  return rc ? rc : rt_write_ppm(path, rgb.data(), width, height);
+}
 int rt_read_aov(rt_renderer* r, uint32_t samp, uint32_t depth, uint32_t* triIdOut, uint8_t* shadowOut)
 {
   if (!r)

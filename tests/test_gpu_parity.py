@@ -255,3 +255,16 @@ def test_full_size_properties_of_the_benchmark_configuration():
     img = a.image()
     np.testing.assert_allclose(img, np.power(np.maximum(acc, 0), np.float32(0.45)), rtol=3e-6, atol=1e-7)
     a.close(), b.close()
+
+
+def test_saved_image_is_the_tonemapped_frame(tmp_path):
+    spec = scenes.cube_scene()
+    r = _render(spec, 96, 64, 2, 3)
+    path = tmp_path / "frame.ppm"
+    r.save_image(str(path))
+    data = path.read_bytes()
+    assert data.startswith(b"P6\n96 64\n255\n")
+    px = np.frombuffer(data[len(b"P6\n96 64\n255\n"):], np.uint8).reshape(64, 96, 3)
+    want = np.floor(np.clip(r.image(), 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+    assert np.array_equal(px, want) and px.max() > 100
+    r.close()

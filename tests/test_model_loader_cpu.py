@@ -118,3 +118,16 @@ def test_shipped_fbx_models():
     box = ra.Mesh.load_all(os.path.join(REF_MODELS, "box.fbx"))
     _check(box, fbx_util.parse_fbx(open(os.path.join(REF_MODELS, "box.fbx"), "rb").read()))
     assert [(m.num_positions, m.num_triangles) for m in box] == [(28, 14)] + [(4, 2)] * 5
+
+
+def test_ppm_encoder(tmp_path):
+    img = np.zeros((3, 5, 3), np.float32)
+    img[0, 0] = (0.0, 0.5, 1.0)
+    img[1, 2] = (-1.0, 2.0, np.nan)
+    img[2, 4] = (0.2, 0.999, 0.001)
+    path = tmp_path / "t.ppm"
+    ra.capi.write_ppm(str(path), img)
+    data = path.read_bytes()
+    assert data.startswith(b"P6\n5 3\n255\n") and len(data) == 11 + 45
+    px = np.frombuffer(data[11:], np.uint8).reshape(3, 5, 3)
+    assert px[0, 0].tolist() == [0, 128, 255] and px[1, 2].tolist() == [0, 255, 0] and px[2, 4].tolist() == [51, 255, 0]
