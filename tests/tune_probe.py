@@ -7,7 +7,11 @@ from tests import scenes
 
 
 def run(spec, W, H, N, depth):
-    r = spec.build_product(options=dict(maxDepth=depth))
+    opts = dict(maxDepth=depth)
+    for name in ("maxLeafTriangles", "sahBins"):
+        if os.environ.get("RT_" + name) is not None:
+            opts[name] = int(os.environ["RT_" + name])
+    r = spec.build_product(options=opts)
     cam = spec.product_camera()
     best = 1e9
     for rep in range(4):
