@@ -1,4 +1,5 @@
 #include "scene/Renderer.h"
+#include <numeric>
 
 namespace rt
 {
@@ -20,6 +21,14 @@ void Renderer::startRender(Camera cam, RenderParameter params)
     render(cam, params);
     running = false;
   });
+}
+
+float Renderer::getLastSampleTime() const { return sampleTimes.empty() ? 0.0f : sampleTimes.back(); }
+
+float Renderer::getAverageSampleTime() const
+{
+  // (the reference divides by size() unconditionally and yields NaN before the first pass; an empty history reads 0 here)
+  return sampleTimes.empty() ? 0.0f : std::accumulate(sampleTimes.begin(), sampleTimes.end(), 0.0f) / (float)sampleTimes.size();
 }
 
 void Renderer::waitRender()
