@@ -146,8 +146,10 @@ def main():
 
     def step():
         if not dynamic:
+            # frames are queued back to back on the context's stream (no host round trip inside a frame or between
+            # frames); the timed region ends with a synchronisation, and a multi-GPU step waits below when it copies
             r.begin_frame(cam, width, height, spp)
-            r.render_passes(0, spp)
+            r.enqueue_passes(0, spp)
         if world > 1 and not dynamic:
             # The gather of frame k travels while frame k+1 renders: the accumulator is copied into one of two staging
             # buffers, the collective is started asynchronously, and rank 0 re-tiles a frame one step later (or in drain()).

@@ -58,6 +58,10 @@ int rt_cancel_render(rt_renderer*);   /* running = false + join (Renderer.cpp:13
  * reports the device time of the call */
 int rt_begin_frame(rt_renderer*, const rthip_camera* camera, uint32_t width, uint32_t height, uint32_t numSamples);
 int rt_render_passes(rt_renderer*, uint32_t begin, uint32_t count, float* msOut);
+/* the same without waiting for the device: passes -- and whole frames, rt_begin_frame included -- queue up behind each other;
+ * rt_synchronize (or any read-back call) waits for everything queued so far */
+int rt_enqueue_passes(rt_renderer*, uint32_t begin, uint32_t count);
+int rt_synchronize(rt_renderer*);
 uint32_t rt_get_sample_times(rt_renderer*, float* msOut, uint32_t cap);        /* ::getSampleTimes */
 int rt_read_accumulator(rt_renderer*, float* rgbOut);                          /* CPURenderer::accumulator */
 int rt_read_image(rt_renderer*, float* rgbOut);                                /* CPURenderer::image */

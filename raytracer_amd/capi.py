@@ -129,6 +129,8 @@ def host_lib():
         L.rt_start_render.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32]
         L.rt_begin_frame.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32]
         L.rt_render_passes.argtypes = [vp, C.c_uint32, C.c_uint32, fp]
+        L.rt_enqueue_passes.argtypes = [vp, C.c_uint32, C.c_uint32]
+        L.rt_synchronize.argtypes = [vp]
         L.rt_wait_render.argtypes = [vp]
         L.rt_cancel_render.argtypes = [vp]
         L.rt_get_sample_times.restype = C.c_uint32
@@ -293,6 +295,13 @@ class Renderer:
     def begin_frame(self, camera, width, height, num_samples):
         self._size = (int(height), int(width))
         _check(host_lib().rt_begin_frame(self._h, C.byref(camera), int(width), int(height), int(num_samples)), "rt_begin_frame")
+
+    def enqueue_passes(self, begin, count):
+        """Queues sample passes [begin, begin+count) without waiting; synchronize() or any read-back waits for them."""
+        _check(host_lib().rt_enqueue_passes(self._h, int(begin), int(count)), "rt_enqueue_passes")
+
+    def synchronize(self):
+        _check(host_lib().rt_synchronize(self._h), "rt_synchronize")
 
     def render_passes(self, begin, count):
         """Runs sample passes [begin, begin+count) synchronously; returns the device milliseconds of the call."""

@@ -1097,6 +1097,25 @@ __global__ __launch_bounds__(kBlock) void k_untile(FrameGeom g, const float* til
 }
 
 // ------------------------------------------------------------------------------------------------ probes
+// adds one batch's tallies to the frame totals (device memory), so a frame needs no host round trip between batches
+__global__ void k_fold_counters(const DeviceCounters* batch, rthip_counters* totals)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0)
+    return;
+  totals->extendPrimary += batch->extendPrimary;
+  totals->extendSecondary += batch->extendSecondary;
+  totals->shadow += batch->shadow;
+  totals->nodesVisited += batch->nodesVisited;
+  totals->trisTested += batch->trisTested;
+  totals->nonFiniteAccepts += batch->nonFinite;
+  totals->nodesVisitedExtend += batch->nodesExtend;
+  totals->trisTestedExtend += batch->trisExtend;
+  totals->waveNodeSteps += batch->waveNodeSteps;
+  totals->waveLeafSteps += batch->waveLeafSteps;
+  for (int i = 0; i < 16; ++i)
+    totals->hits[i] += batch->hits[i];
+}
+
 __global__ void k_probe_rand01(const uint32_t* xyz, uint32_t n, float* out)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1228,7 +1247,7 @@ struct rthip_ctx
   bool countWork = false, kernelTiming = false;
   float kernelMs[6] = {};
   uint32_t kernelLaunches[6] = {};
-  rthip_counters totals{};
+  DevBuf<rthip_counters> totals; // frame totals, device memory (read back by rthip_get_counters)
 };
 
 namespace
@@ -1364,22 +1383,6 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   return (int)hipGetLastError();
 }
 
-void addCounters(rthip_counters& dst, const DeviceCounters& s)
-{
-  dst.extendPrimary += s.extendPrimary;
-  dst.extendSecondary += s.extendSecondary;
-  dst.shadow += s.shadow;
-  dst.nodesVisited += s.nodesVisited;
-  dst.trisTested += s.trisTested;
-  dst.nonFiniteAccepts += s.nonFinite;
-  dst.nodesVisitedExtend += s.nodesExtend;
-  dst.trisTestedExtend += s.trisExtend;
-  dst.waveNodeSteps += s.waveNodeSteps;
-  dst.waveLeafSteps += s.waveLeafSteps;
-  for (int i = 0; i < 16; ++i)
-    dst.hits[i] += s.hits[i];
-}
-
 // one batch of `count` sample passes starting at sampBegin
 int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count)
 {
@@ -1501,19 +1504,12 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count)
     hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->geom, pathBuffers(c), c->acc.p, count);
     HIPCHK(hipGetLastError());
   }
+  hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, c->stream, c->counters.p, c->totals.p);
+  HIPCHK(hipGetLastError());
   c->lastBatchBegin = sampBegin;
   c->lastBatchCount = count;
   c->lastSamp = sampBegin + count - 1;
   c->renderedAny = true;
-  return 0;
-}
-
-int foldCounters(rthip_ctx* c)
-{
-  DeviceCounters dc;
-  HIPCHK(hipMemcpyAsync(&dc, c->counters.p, sizeof(dc), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  addCounters(c->totals, dc);
   return 0;
 }
 
@@ -1531,9 +1527,7 @@ int renderPasses(rthip_ctx* c, uint32_t sampBegin, uint32_t count, bool sync)
     int rc = renderBatch(c, sampBegin + done, n);
     if (rc)
       return rc;
-    rc = foldCounters(c); // also drains the batch so its path buffers can be reused
-    if (rc)
-      return rc;
+    // (the next batch reuses the path buffers: same stream, so it runs after this one)
     done += n;
   }
   if (sync)
@@ -1608,7 +1602,7 @@ int rthip_destroy(rthip_ctx* c)
   c->modelNodes.release(), c->nodes.release(), c->tris.release(), c->lights.release(), c->tileIds.release(), c->camConsts.release();
   c->rayO.release(), c->rayD.release(), c->s0.release(), c->s1.release(), c->nz.release(), c->hit.release(), c->live.release(), c->mask.release();
   c->anyOut.release(), c->acc.release(), c->img.release(), c->rowScratch.release(), c->aovTri.release(), c->aovShadow.release();
-  c->spill.release(), c->fetch.release(), c->listA.release(), c->listB.release(), c->counters.release();
+  c->spill.release(), c->spill2.release(), c->fetch.release(), c->listA.release(), c->listB.release(), c->counters.release(), c->totals.release();
   (void)hipEventDestroy(c->evA), (void)hipEventDestroy(c->evB), (void)hipEventDestroy(c->evK0), (void)hipEventDestroy(c->evK1);
   (void)hipEventDestroy(c->evFork), (void)hipEventDestroy(c->evJoin);
   (void)hipStreamDestroy(c->stream2);
@@ -1700,7 +1694,8 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
       return RTHIP_E_BOUNDS;
   }
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  // No host synchronisation here: a frame is enqueued behind the previous one on the context's stream, so a caller that
+  // uses rthip_enqueue_passes keeps the GPU busy across frames (buffers only ever grow, and growing one synchronises).
   const uint32_t tilesX = (f->width + ts - 1) / ts, tilesY = (f->height + ts - 1) / ts;
   FrameGeom g{};
   g.width = f->width, g.height = f->height, g.numSamples = f->numSamples;
@@ -1739,6 +1734,7 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
       xy[k] = ((c->hostTileIds[k] % tilesX) * ts) | (((c->hostTileIds[k] / tilesX) * ts) << 16);
     if (xy != c->hostTileXY) // frames of one animation keep their tiling: upload the table only when it changes
     {
+      HIPCHK(hipStreamSynchronize(c->stream)); // kernels of the previous frame may still read the old table
       HIPCHK(hipMemcpy(c->tileIds.p, xy.data(), sizeof(uint32_t) * g.numLocalTiles, hipMemcpyHostToDevice));
       c->hostTileXY.swap(xy);
     }
@@ -1761,7 +1757,8 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
   if ((uint64_t)c->batchCap * g.numLocalTiles * g.numLocalTiles >= (1ull << 32))
     return RTHIP_E_LIMIT;
   const size_t numSlots = (size_t)P64 * c->batchCap;
-  if ((rc = ensurePathBuffers(c, numSlots)) || (rc = c->acc.ensure(P64 * 3)) || (rc = c->img.ensure(P64 * 3)) || (rc = c->camConsts.ensure(1)))
+  if ((rc = ensurePathBuffers(c, numSlots)) || (rc = c->acc.ensure(P64 * 3)) || (rc = c->img.ensure(P64 * 3)) || (rc = c->camConsts.ensure(1)) ||
+      (rc = c->totals.ensure(1)))
     return rc;
   if (c->aovDepths)
   {
@@ -1771,7 +1768,7 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
   HIPCHK(hipMemsetAsync(c->acc.p, 0, P64 * 3 * sizeof(float), c->stream)); // CPURenderer.cpp:142-143 (image is made on read)
   hipLaunchKernelGGL(k_camera, dim3(1), dim3(64), 0, c->stream, *camera, c->camConsts.p);
   HIPCHK(hipGetLastError());
-  std::memset(&c->totals, 0, sizeof(c->totals));
+  HIPCHK(hipMemsetAsync(c->totals.p, 0, sizeof(rthip_counters), c->stream));
   std::memset(c->kernelMs, 0, sizeof(c->kernelMs));
   std::memset(c->kernelLaunches, 0, sizeof(c->kernelLaunches));
   c->renderedAny = false;
@@ -1869,6 +1866,7 @@ int rthip_read_aov(rthip_ctx* c, uint32_t samp, uint32_t depth, uint32_t* triIdO
   const size_t off = ((size_t)(samp - c->lastBatchBegin) * c->aovDepths + depth) * P;
   std::vector<uint32_t> tri(P);
   std::vector<uint8_t> sh(P);
+  HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(tri.data(), c->aovTri.p + off, P * sizeof(uint32_t), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(sh.data(), c->aovShadow.p + off, P, hipMemcpyDeviceToHost));
   const FrameGeom& g = c->geom;
@@ -1953,7 +1951,14 @@ int rthip_get_counters(rthip_ctx* c, rthip_counters* out)
 {
   if (!c || !out)
     return RTHIP_E_ARG;
-  *out = c->totals;
+  if (!c->haveFrame)
+  {
+    std::memset(out, 0, sizeof(*out));
+    return 0;
+  }
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(out, c->totals.p, sizeof(*out), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 

@@ -237,6 +237,8 @@ int rt_render_passes(rt_renderer* r, uint32_t begin, uint32_t count, float* msOu
     return RTHIP_E_ARG;
   return r->hip->renderPasses(begin, count, msOut);
 }
+int rt_enqueue_passes(rt_renderer* r, uint32_t begin, uint32_t count) { return r ? r->hip->enqueuePasses(begin, count) : RTHIP_E_ARG; }
+int rt_synchronize(rt_renderer* r) { return r ? r->hip->synchronize() : RTHIP_E_ARG; }
 int rt_wait_render(rt_renderer* r)
 {
   if (!r)

@@ -61,6 +61,18 @@ int HIPRenderer::renderPasses(uint32_t begin, uint32_t count, float* ms)
   return error;
 }
 
+int HIPRenderer::enqueuePasses(uint32_t begin, uint32_t count)
+{
+  if (!ctx)
+    return error = RTHIP_E_NODEVICE;
+  error = rthip_enqueue_passes(ctx, begin, count);
+  if (error)
+    std::fprintf(stderr, "HIPRenderer: rthip_enqueue_passes: %s\n", rthip_error_string(error));
+  return error;
+}
+
+int HIPRenderer::synchronize() { return ctx ? (error = rthip_synchronize(ctx)) : (error = RTHIP_E_NODEVICE); }
+
 // Takes the place of CPURenderer::render (src/cpu/CPURenderer.cpp:138-207).  The device keeps the accumulator;
 // per-sample-pass times go to sampleTimes as in the reference (:204-205), here device milliseconds of a call
 // divided evenly over the passes it ran.

@@ -45,6 +45,10 @@ public:
   // does what render() does before its loop, renderPasses runs passes [begin, begin+count) and returns device ms
   int beginFrameRender(Camera cam, RenderParameter params);
   int renderPasses(uint32_t begin, uint32_t count, float* ms);
+  // the same without waiting: passes (and whole frames, beginFrameRender included) queue up behind each other on the
+  // context's stream; synchronize() waits for everything queued so far
+  int enqueuePasses(uint32_t begin, uint32_t count);
+  int synchronize();
 
 protected:
   void render(Camera cam, RenderParameter params) override;

@@ -268,3 +268,25 @@ def test_saved_image_is_the_tonemapped_frame(tmp_path):
     want = np.floor(np.clip(r.image(), 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
     assert np.array_equal(px, want) and px.max() > 100
     r.close()
+
+
+def test_frames_queued_without_waiting_give_the_same_bits():
+    """rt_enqueue_passes: three different frames queued back to back (no host synchronisation in between); the last one
+    must equal a blocking render of the same frame, counters included (the totals live on the device)."""
+    spec = scenes.multi_model_scene()
+    W, H, N, depth = 160, 128, 3, 1  # depth cap 1: a frame needs no host round trip at all
+    ref = _render(spec, W, H, N, depth)
+    want_acc, want_cnt = ref.accumulator(), ref.counters()
+    ref.close()
+    r = spec.build_product(options=dict(maxDepth=depth))
+    cam = spec.product_camera()
+    other = ra.make_camera(position=(2.0, 1.0, 7.0), target=(0, 0, 0), S_O=6, f=0, A=0)
+    for camera in (other, cam, other, cam):
+        r.begin_frame(camera, W, H, N)
+        r.enqueue_passes(0, 2)
+        r.enqueue_passes(2, N - 2)
+    got_cnt = r.counters()  # synchronises
+    assert np.array_equal(r.accumulator().view(np.uint32), want_acc.view(np.uint32))
+    for k in ("extendPrimary", "extendSecondary", "shadow", "hits"):
+        assert got_cnt[k] == want_cnt[k]
+    r.close()
