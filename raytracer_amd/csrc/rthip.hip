@@ -179,8 +179,12 @@ __device__ __forceinline__ vec3 foldLights(const Lights* lights, uint32_t occlud
 }
 
 // ------------------------------------------------------------------------------------------------ set-up kernels
-__global__ void k_camera(rthip_camera cam, CameraConsts* out)
+// also clears the frame's counter totals (one dispatch less in the frame prologue)
+__global__ void k_camera(rthip_camera cam, CameraConsts* out, rthip_counters* totals)
 {
+  if (totals && blockIdx.x == 0)
+    for (uint32_t i = threadIdx.x; i < sizeof(rthip_counters) / sizeof(uint64_t); i += blockDim.x)
+      reinterpret_cast<uint64_t*>(totals)[i] = 0;
   if (threadIdx.x == 0 && blockIdx.x == 0)
     *out = rtd::cameraSetup(cam);
 }
@@ -1041,13 +1045,14 @@ __global__ __launch_bounds__(kBlock) void k_compact(PathBuffers pb, uint32_t num
 }
 
 // accumulator[pix] += radiance / float(N), sample passes in ascending order (CPURenderer.cpp:197)
-__global__ __launch_bounds__(kBlock) void k_accumulate(FrameGeom g, PathBuffers pb, float* acc, uint32_t numBatchSamples)
+// `fresh` = first batch of a frame: the accumulator is taken as zero instead of being loaded (saves clearing it beforehand)
+__global__ __launch_bounds__(kBlock) void k_accumulate(FrameGeom g, PathBuffers pb, float* acc, uint32_t numBatchSamples, uint32_t fresh)
 {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= g.numLocalPixels)
     return;
   float r = 0, gg = 0, b = 0;
-  bool loaded = false;
+  bool loaded = fresh != 0; // 0 + x == x and 0 + 0 == +0: starting from zero is what the cleared accumulator would give
   const float n = float(g.numSamples);
   for (uint32_t s = 0; s < numBatchSamples; ++s)
   {
@@ -1231,7 +1236,8 @@ struct rthip_ctx
   DevBuf<float> acc, img, rowScratch;
   DevBuf<uint32_t> aovTri;
   DevBuf<uint8_t> aovShadow;
-  DevBuf<uint32_t> spill, fetch;
+  DevBuf<uint32_t> spill;
+  DevBuf<uint32_t> fetch;        // [batch counters (kCounterWords) | work-fetch counters]: everything a batch zeroes, one memset
   DevBuf<uint32_t> spill2;       // stack spill area of launches on stream2
   DevBuf<uint32_t> listA, listB; // sparse-mode slot lists (even / odd depth)
   uint32_t spillCap = 1;         // per-lane spill entries the uploaded BVH can need
@@ -1241,9 +1247,9 @@ struct rthip_ctx
   uint32_t tuneSteal = 1; // spans a wave may pull chunks from (1 = its own only; stealing measured +4% on the 1M soup, -4% on the bunny: off)
   uint32_t tuneRefill = kRefillThreshold, tuneLeaf = kLeafTrigger;
   bool fusedPrimary = true;      // generate rays inside the depth-0 traversal kernel instead of storing them
-  DevBuf<DeviceCounters> counters;
   uint32_t lastBatchBegin = 0, lastBatchCount = 0, lastSamp = 0;
   bool renderedAny = false;
+  bool accFresh = false;         // the accumulator has not been written this frame: the first k_accumulate starts from zero
   bool countWork = false, kernelTiming = false;
   float kernelMs[6] = {};
   uint32_t kernelLaunches[6] = {};
@@ -1263,6 +1269,10 @@ DeviceScene devScene(const rthip_ctx* c)
   s.cullAbs = c->info.cullAbs;
   return s;
 }
+constexpr size_t kCounterWords = ((sizeof(DeviceCounters) + 255) / 256) * 64; // DeviceCounters rounded up to 256 B, in words
+DeviceCounters* batchCounters(const rthip_ctx* c) { return reinterpret_cast<DeviceCounters*>(c->fetch.p); }
+uint32_t* fetchBase(const rthip_ctx* c) { return c->fetch.p + kCounterWords; }
+
 PathBuffers pathBuffers(const rthip_ctx* c)
 {
   PathBuffers pb;
@@ -1322,12 +1332,12 @@ int ensurePathBuffers(rthip_ctx* c, size_t numSlots)
   blocks = std::max(blocks, c->traceBlocks);
   if ((rc = c->spill.ensure((size_t)c->spillCap * blocks * kBlock)) || (rc = c->spill2.ensure((size_t)c->spillCap * blocks * kBlock)))
     return rc;
-  if ((rc = c->fetch.ensure((size_t)kMaxTraceLaunches * kFetchShards * kFetchStride)))
+  if ((rc = c->fetch.ensure(kCounterWords + (size_t)kMaxTraceLaunches * kFetchShards * kFetchStride)))
     return rc;
   c->sparseCap = (uint32_t)std::max<size_t>(4096, numSlots / 32);
   if ((rc = c->listA.ensure(c->sparseCap)) || (rc = c->listB.ensure(c->sparseCap)))
     return rc;
-  return c->counters.ensure(1);
+  return 0;
 }
 
 // list == nullptr: dense launch over all numSlots slots; otherwise sparse launch over the device-side list whose
@@ -1345,10 +1355,10 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   a.sampBegin = sampBegin;
   a.numSlots = numSlots;
   a.list = list;
-  a.listCount = list ? &c->counters.p->listCount[depth] : nullptr;
+  a.listCount = list ? &batchCounters(c)->listCount[depth] : nullptr;
   a.depth = depth;
   a.spill = sideStream ? c->spill2.p : c->spill.p;
-  a.counters = c->counters.p;
+  a.counters = batchCounters(c);
   a.tmin = tmin;
   a.tmax = tmax;
   a.anyOut = c->anyOut.p;
@@ -1370,7 +1380,7 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
     dynamicGeometry(c, list ? bound : numSlots, blocks, a.chunkLen);
     if (c->fetchCursor >= kMaxTraceLaunches)
       return RTHIP_E_LIMIT;
-    a.fetch = c->fetch.p + (size_t)(c->fetchCursor++) * kFetchShards * kFetchStride;
+    a.fetch = fetchBase(c) + (size_t)(c->fetchCursor++) * kFetchShards * kFetchStride;
   }
   if ((size_t)c->spillCap * blocks * kBlock > c->spill.n)
     return RTHIP_E_LIMIT;
@@ -1389,8 +1399,7 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count)
   const uint32_t P = c->geom.numLocalPixels;
   const uint32_t numSlots = P * count;
   const uint32_t shadeBlocksDense = std::max(1u, std::min((numSlots + kBlock - 1) / kBlock, (uint32_t)c->numCUs * 8u));
-  HIPCHK(hipMemsetAsync(c->counters.p, 0, sizeof(DeviceCounters), c->stream));
-  HIPCHK(hipMemsetAsync(c->fetch.p, 0, c->fetch.n * sizeof(uint32_t), c->stream));
+  HIPCHK(hipMemsetAsync(c->fetch.p, 0, c->fetch.n * sizeof(uint32_t), c->stream)); // batch counters + work-fetch counters
   c->fetchCursor = 0;
   if (c->aovDepths)
   {
@@ -1412,7 +1421,7 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count)
   sa.pb = pathBuffers(c);
   sa.lights = c->lights.p;
   sa.cam = c->camConsts.p;
-  sa.counters = c->counters.p;
+  sa.counters = batchCounters(c);
   sa.numSlots = numSlots;
   sa.maxDepth = c->maxDepth;
   sa.sampBegin = sampBegin;
@@ -1484,7 +1493,7 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count)
       // how many paths go on?  stop when none do; switch to slot lists when few do (open scenes lose most paths
       // within a bounce or two, and scanning every slot's liveness byte for a handful of paths is wasted work)
       unsigned long long alive = 0;
-      HIPCHK(hipMemcpyAsync(&alive, &c->counters.p->alive[d + 1], sizeof(alive), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpyAsync(&alive, &batchCounters(c)->alive[d + 1], sizeof(alive), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       if (alive == 0)
         break;
@@ -1493,7 +1502,7 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count)
       {
         KernelTimer kt(c, 5);
         hipLaunchKernelGGL(k_compact, dim3((numSlots + kBlock * 16 - 1) / (kBlock * 16)), dim3(kBlock), 0, c->stream, pathBuffers(c), numSlots,
-                           d + 1, listNext, c->sparseCap, c->counters.p);
+                           d + 1, listNext, c->sparseCap, batchCounters(c));
         HIPCHK(hipGetLastError());
         sparse = true;
       }
@@ -1501,10 +1510,11 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count)
   }
   {
     KernelTimer kt(c, 4);
-    hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->geom, pathBuffers(c), c->acc.p, count);
+    hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->geom, pathBuffers(c), c->acc.p, count, c->accFresh ? 1u : 0u);
+    c->accFresh = false;
     HIPCHK(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, c->stream, c->counters.p, c->totals.p);
+  hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, c->stream, batchCounters(c), c->totals.p);
   HIPCHK(hipGetLastError());
   c->lastBatchBegin = sampBegin;
   c->lastBatchCount = count;
@@ -1602,7 +1612,7 @@ int rthip_destroy(rthip_ctx* c)
   c->modelNodes.release(), c->nodes.release(), c->tris.release(), c->lights.release(), c->tileIds.release(), c->camConsts.release();
   c->rayO.release(), c->rayD.release(), c->s0.release(), c->s1.release(), c->nz.release(), c->hit.release(), c->live.release(), c->mask.release();
   c->anyOut.release(), c->acc.release(), c->img.release(), c->rowScratch.release(), c->aovTri.release(), c->aovShadow.release();
-  c->spill.release(), c->spill2.release(), c->fetch.release(), c->listA.release(), c->listB.release(), c->counters.release(), c->totals.release();
+  c->spill.release(), c->spill2.release(), c->fetch.release(), c->listA.release(), c->listB.release(), c->totals.release();
   (void)hipEventDestroy(c->evA), (void)hipEventDestroy(c->evB), (void)hipEventDestroy(c->evK0), (void)hipEventDestroy(c->evK1);
   (void)hipEventDestroy(c->evFork), (void)hipEventDestroy(c->evJoin);
   (void)hipStreamDestroy(c->stream2);
@@ -1765,10 +1775,9 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
     if ((rc = c->aovTri.ensure(numSlots * c->aovDepths)) || (rc = c->aovShadow.ensure(numSlots * c->aovDepths)))
       return rc;
   }
-  HIPCHK(hipMemsetAsync(c->acc.p, 0, P64 * 3 * sizeof(float), c->stream)); // CPURenderer.cpp:142-143 (image is made on read)
-  hipLaunchKernelGGL(k_camera, dim3(1), dim3(64), 0, c->stream, *camera, c->camConsts.p);
+  c->accFresh = true; // CPURenderer.cpp:142-143: the clear is folded into the first k_accumulate (or done on a read before it)
+  hipLaunchKernelGGL(k_camera, dim3(1), dim3(64), 0, c->stream, *camera, c->camConsts.p, c->totals.p);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemsetAsync(c->totals.p, 0, sizeof(rthip_counters), c->stream));
   std::memset(c->kernelMs, 0, sizeof(c->kernelMs));
   std::memset(c->kernelLaunches, 0, sizeof(c->kernelLaunches));
   c->renderedAny = false;
@@ -1810,6 +1819,17 @@ int rthip_synchronize(rthip_ctx* c)
   return 0;
 }
 
+// the accumulator is cleared lazily: by the first k_accumulate of a frame, or here when it is read before that
+static int settleAccumulator(rthip_ctx* c)
+{
+  if (c->accFresh)
+  {
+    HIPCHK(hipMemsetAsync(c->acc.p, 0, c->acc.n * sizeof(float), c->stream));
+    c->accFresh = false;
+  }
+  return 0;
+}
+
 static int readTiled(rthip_ctx* c, const float* tileMajorDev, float* rgbOut)
 {
   const size_t full = (size_t)c->geom.width * c->geom.height * 3;
@@ -1833,6 +1853,8 @@ int rthip_read_accumulator(rthip_ctx* c, float* rgbOut)
   if (!c->haveFrame)
     return RTHIP_E_STATE;
   HIPCHK(hipSetDevice(c->device));
+  if (int rc = settleAccumulator(c))
+    return rc;
   return readTiled(c, c->acc.p, rgbOut);
 }
 
@@ -1844,12 +1866,11 @@ int rthip_read_image(rthip_ctx* c, float* rgbOut)
     return RTHIP_E_STATE;
   HIPCHK(hipSetDevice(c->device));
   const uint32_t nf = c->geom.numLocalPixels * 3;
-  const float resolver = float(c->geom.numSamples) / float(c->lastSamp + 1); // CPURenderer.cpp:196
-  if (c->renderedAny)
-  {
-    hipLaunchKernelGGL(k_tonemap, dim3((nf + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->acc.p, c->img.p, nf, resolver);
-    HIPCHK(hipGetLastError());
-  }
+  if (int rc = settleAccumulator(c))
+    return rc;
+  const float resolver = c->renderedAny ? float(c->geom.numSamples) / float(c->lastSamp + 1) : 1.0f; // CPURenderer.cpp:196
+  hipLaunchKernelGGL(k_tonemap, dim3((nf + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->acc.p, c->img.p, nf, resolver);
+  HIPCHK(hipGetLastError());
   return readTiled(c, c->img.p, rgbOut);
 }
 
@@ -1894,6 +1915,9 @@ int rthip_accumulator_device(rthip_ctx* c, float** devPtr, uint64_t* numFloats)
     return RTHIP_E_ARG;
   if (!c->haveFrame)
     return RTHIP_E_STATE;
+  HIPCHK(hipSetDevice(c->device));
+  if (int rc = settleAccumulator(c))
+    return rc;
   *devPtr = c->acc.p;
   *numFloats = (uint64_t)c->geom.numLocalPixels * 3;
   return 0;
@@ -1908,6 +1932,8 @@ int rthip_copy_accumulator_to(rthip_ctx* c, float* dstDev, uint64_t numFloats)
   if (numFloats != (uint64_t)c->geom.numLocalPixels * 3)
     return RTHIP_E_ARG;
   HIPCHK(hipSetDevice(c->device));
+  if (int rc = settleAccumulator(c))
+    return rc;
   HIPCHK(hipMemcpyAsync(dstDev, c->acc.p, numFloats * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
@@ -2050,7 +2076,7 @@ int rthip_probe_primary_rays(rthip_ctx* c, const rthip_camera* cam, uint32_t wid
   if ((rc = in.ensure(3 * (size_t)n)) || (rc = o.ensure(3 * (size_t)n)) || (rc = d.ensure(3 * (size_t)n)) || (rc = kc.ensure(1)))
     return rc;
   HIPCHK(hipMemcpy(in.p, whs, 3 * (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_camera, dim3(1), dim3(64), 0, c->stream, *cam, kc.p);
+  hipLaunchKernelGGL(k_camera, dim3(1), dim3(64), 0, c->stream, *cam, kc.p, (rthip_counters*)nullptr);
   hipLaunchKernelGGL(k_probe_rays, dim3((n + 255) / 256), dim3(256), 0, c->stream, kc.p, width, height, in.p, n, o.p, d.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -2098,8 +2124,7 @@ int rthip_probe_trace(rthip_ctx* c, const float* origin3, const float* dir3, uin
     return rc;
   HIPCHK(hipMemcpy(o.p, origin3, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d.p, dir3, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-  HIPCHK(hipMemsetAsync(c->counters.p, 0, sizeof(DeviceCounters), c->stream));
-  HIPCHK(hipMemsetAsync(c->fetch.p, 0, c->fetch.n * sizeof(uint32_t), c->stream));
+  HIPCHK(hipMemsetAsync(c->fetch.p, 0, c->fetch.n * sizeof(uint32_t), c->stream)); // batch counters + work-fetch counters
   c->fetchCursor = 0;
   hipLaunchKernelGGL(k_probe_pack, dim3((n + 255) / 256), dim3(256), 0, c->stream, o.p, d.p, n, c->rayO.p, c->rayD.p, c->live.p);
   HIPCHK(hipGetLastError());

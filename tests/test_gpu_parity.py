@@ -290,3 +290,16 @@ def test_frames_queued_without_waiting_give_the_same_bits():
     for k in ("extendPrimary", "extendSecondary", "shadow", "hits"):
         assert got_cnt[k] == want_cnt[k]
     r.close()
+
+
+def test_accumulator_and_image_read_before_any_pass_are_zero():
+    spec = scenes.cube_scene()
+    r = spec.build_product(options=dict(maxDepth=2))
+    r.begin_frame(spec.product_camera(), 100, 70, 4)
+    assert not r.accumulator().any() and not r.image().any()
+    r.render_passes(0, 1)  # the first pass after that early read must still start from zero
+    first = r.accumulator()
+    r.begin_frame(spec.product_camera(), 100, 70, 4)
+    r.render_passes(0, 1)
+    assert np.array_equal(first.view(np.uint32), r.accumulator().view(np.uint32)) and first.any()
+    r.close()
