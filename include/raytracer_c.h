@@ -45,7 +45,7 @@ int rt_add_mesh(rt_renderer*, const rt_mesh*, const float transform[16]);
 int rt_generate(rt_renderer*);                                                 /* Renderer::generate */
 
 /* options the reference hard-codes: name in {"maxDepth","aovDepths","tileSize","passesPerCall",
- * "referenceEdgeIndexing","maxLeafTriangles","sahBins","buildThreads","originBoundScale","countWork","kernelTiming","fusedPrimary"};
+ * "referenceEdgeIndexing","maxLeafTriangles","sahBins","buildThreads","originBoundScale","countWork","kernelTiming","fusedPrimary","pipelining"};
  * scene options must be set before rt_generate */
 int rt_set_option(rt_renderer*, const char* name, double value);
 int rt_set_tiles(rt_renderer*, const uint32_t* tileIds, uint32_t numTiles);    /* tiles this renderer owns; 0 = all */

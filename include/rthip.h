@@ -123,6 +123,9 @@ int rthip_set_work_counting(rthip_ctx* ctx, int enabled);
 /* 1 (default): primary rays are generated inside the depth-0 extend kernel and never stored;
  * 0: a stand-alone generate kernel writes them first (the A/B baseline) */
 int rthip_set_fused_primary(rthip_ctx* ctx, int enabled);
+/* 1 (default): with a depth cap of 1 a call's passes are split in two pieces that run on two sets of path buffers and two
+ * streams, and consecutive frames overlap; 0: one batch at a time (the A/B baseline; results are bit-identical) */
+int rthip_set_pipelining(rthip_ctx* ctx, int enabled);
 /* per-kernel device milliseconds accumulated since rthip_begin (HIP events around every launch when enabled):
  * order generate, extend, shade, shadow, accumulate, compact.  enable with rthip_set_kernel_timing(ctx,1). */
 int rthip_set_kernel_timing(rthip_ctx* ctx, int enabled);

@@ -303,3 +303,25 @@ def test_accumulator_and_image_read_before_any_pass_are_zero():
     r.render_passes(0, 1)
     assert np.array_equal(first.view(np.uint32), r.accumulator().view(np.uint32)) and first.any()
     r.close()
+
+
+@pytest.mark.parametrize("name,N", [("multi", 5), ("bunny", 4)])
+def test_pipelined_batches_match_oracle_and_the_unpipelined_path(name, N):
+    """Depth cap 1: a call's passes run as two pieces on two slots and consecutive frames overlap; the accumulator must be
+    what one batch at a time gives, which must be what the oracle gives."""
+    spec = {"multi": scenes.multi_model_scene, "bunny": scenes.bunny_scene}[name]()
+    W, H = 200, 152
+    want = spec.build_oracle().render(spec.oracle_camera(), W, H, N, max_depth=1, workers=14)
+    accs = {}
+    for pipelining in (1, 0):
+        r = spec.build_product(options=dict(maxDepth=1, pipelining=pipelining))
+        for _ in range(3):  # three frames back to back: the second and third overlap their predecessor
+            r.begin_frame(spec.product_camera(), W, H, N)
+            r.enqueue_passes(0, N)
+        accs[pipelining] = r.accumulator()
+        cnt = r.counters()
+        assert cnt["extendPrimary"] == want["counters"]["extendPrimary"] and cnt["shadow"] == want["counters"]["shadow"]
+        assert cnt["hits"][0] == want["counters"]["hits"][0]
+        r.close()
+    assert np.array_equal(accs[1].view(np.uint32), accs[0].view(np.uint32))
+    assert np.array_equal(accs[1].view(np.uint32), want["accumulator"].view(np.uint32))

@@ -1,1 +1,3 @@
-for leaf in 1 2 3 4 6 8; do echo "maxLeafTriangles $leaf"; RT_maxLeafTriangles=$leaf timeout -k 10 200 python3 -u tests/tune_probe.py soup8 bunny || exit 1; done
+timeout -k 10 100 python3 bench.py --no-cpu-baseline | cut -c1-160
+timeout -k 10 100 python3 bench.py --no-cpu-baseline --workload bunny | cut -c1-160
+RTHIP_TUNE=16,4,6,0,1,0 timeout -k 10 100 python3 bench.py --no-cpu-baseline | cut -c1-160
