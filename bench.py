@@ -259,10 +259,14 @@ def main():
     if args.no_roofline:
         print(json.dumps({"metric": "Mrays/s (primary+secondary)", "value": round(value, 2), "unit": "Mrays/s", "ms_per_step": round(ms_per_step, 4)}), flush=True)
         return
+    # Event pairs around every launch, resolved after the streams have drained: the frames below run exactly like the timed
+    # ones (batches and frames overlapping), so a kernel's average duration here is what rocprofv3 reports for it.
+    T = 5
     r.set_option("kernelTiming", 1)
-    r.begin_frame(cam, width, height, spp)
-    r.render_passes(0, spp)
-    ktimes = r.kernel_times()
+    for _ in range(T):
+        r.begin_frame(cam, width, height, spp)
+        r.enqueue_passes(0, spp)
+    ktimes = {k: (ms / T, launches / T) for k, (ms, launches) in r.kernel_times().items()}
     r.set_option("kernelTiming", 0)
     r.set_option("countWork", 1)
     r.begin_frame(cam, width, height, spp)
@@ -297,8 +301,8 @@ def main():
     roofline = {"bound": "hbm", "kernel": {"extend": "k_trace<PRIMARY|CLOSEST> (extend)", "shadow": "k_trace<SHADOW>", "generate": "k_generate",
                                            "shade": "k_shade", "accumulate": "k_accumulate", "compact": "k_compact"}[dominant],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "valu_issue_utilisation": valu_util, "algorithmic_bytes_per_launch": round(alg_bytes[dominant] / max(1, k_launches), 1),
-                "avg_launch_ms": round(k_ms / max(1, k_launches), 5), "launches_per_step": k_launches,
+                "traffic": traffic, "valu_issue_utilisation": valu_util, "algorithmic_bytes_per_launch": round(alg_bytes[dominant] / max(1e-9, k_launches), 1),
+                "avg_launch_ms": round(k_ms / max(1e-9, k_launches), 5), "launches_per_step": round(k_launches, 2),
                 "nodes_per_extend_ray": round(wc["nodesVisitedExtend"] / max(1, n_ext), 3),
                 "tris_per_extend_ray": round(wc["trisTestedExtend"] / max(1, n_ext), 3),
                 "kernel_ms_per_step": {k: round(v[0], 4) for k, v in ktimes.items()}}

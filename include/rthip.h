@@ -126,8 +126,10 @@ int rthip_set_fused_primary(rthip_ctx* ctx, int enabled);
 /* 1 (default): with a depth cap of 1 a call's passes are split in two pieces that run on two sets of path buffers and two
  * streams, and consecutive frames overlap; 0: one batch at a time (the A/B baseline; results are bit-identical) */
 int rthip_set_pipelining(rthip_ctx* ctx, int enabled);
-/* per-kernel device milliseconds accumulated since rthip_begin (HIP events around every launch when enabled):
- * order generate, extend, shade, shadow, accumulate, compact.  enable with rthip_set_kernel_timing(ctx,1). */
+/* per-kernel device milliseconds and launch counts accumulated since timing was last switched on (HIP event pairs recorded
+ * around every launch on the stream it goes to, resolved when the times are read, so batches and frames overlap exactly as
+ * they do untimed): order generate, extend, shade, shadow, accumulate, compact.  rthip_set_kernel_timing(ctx,1) starts a
+ * fresh measurement; rthip_get_kernel_times waits for the device. */
 int rthip_set_kernel_timing(rthip_ctx* ctx, int enabled);
 int rthip_get_kernel_times(rthip_ctx* ctx, float msOut[6], uint32_t launchesOut[6]);
 

@@ -54,6 +54,7 @@ constexpr uint32_t kMaxTraceLaunches = 2 * (64 + 2); // two traversal launches p
 constexpr uint8_t kDead = 0xff;        // path finished, radiance in s0
 constexpr uint8_t kDeadZero = 0xfe;    // path finished with exactly zero radiance (primary miss) or pixel outside the image
 constexpr uint32_t kMaxLights = 8;
+constexpr size_t kMaxTimedLaunches = 16384; // event pairs kept by the kernel timer between two reads
 constexpr uint32_t kMaxDepthSlots = 64;
 
 enum TraceMode
@@ -1257,6 +1258,8 @@ struct rthip_ctx
   bool accFresh = false;         // the accumulator has not been written this frame: the first k_accumulate starts from zero
   bool countWork = false, kernelTiming = false;
   float kernelMs[6] = {};
+  std::vector<hipEvent_t> timerEvents; // pairs, created on demand (see KernelTimer)
+  std::vector<int> timerLog;           // kernel family of each recorded pair
   uint32_t kernelLaunches[6] = {};
   DevBuf<rthip_counters> totals; // frame totals, device memory (read back by rthip_get_counters)
 
@@ -1334,26 +1337,38 @@ PathBuffers pathBuffers(const rthip_ctx* c)
   return pb;
 }
 
+// Per-kernel timing without stalling anything: an event pair is recorded around a launch on the stream it goes to and
+// logged; the pairs are resolved when the times are read (rthip_get_kernel_times), after the streams have drained.  So
+// batches and frames overlap exactly as they do untimed, and a kernel's time is what rocprofv3 reports for it.
 struct KernelTimer
 {
   rthip_ctx* c;
   int which;
-  KernelTimer(rthip_ctx* ctx, int k) : c(ctx), which(k)
+  hipStream_t stream;
+  int pair = -1;
+  KernelTimer(rthip_ctx* ctx, int k, hipStream_t st = nullptr) : c(ctx), which(k), stream(st ? st : ctx->stream)
   {
-    if (c->kernelTiming)
-      (void)hipEventRecord(c->evK0, c->stream);
+    if (!c->kernelTiming || c->timerLog.size() >= kMaxTimedLaunches)
+      return;
+    pair = (int)c->timerLog.size();
+    while (c->timerEvents.size() < 2 * (size_t)(pair + 1))
+    {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess)
+      {
+        pair = -1;
+        return;
+      }
+      c->timerEvents.push_back(e);
+    }
+    c->timerLog.push_back(which);
+    (void)hipEventRecord(c->timerEvents[2 * (size_t)pair], stream);
   }
   ~KernelTimer()
   {
     c->kernelLaunches[which]++;
-    if (c->kernelTiming)
-    {
-      (void)hipEventRecord(c->evK1, c->stream);
-      (void)hipEventSynchronize(c->evK1);
-      float ms = 0;
-      (void)hipEventElapsedTime(&ms, c->evK0, c->evK1);
-      c->kernelMs[which] += ms;
-    }
+    if (pair >= 0)
+      (void)hipEventRecord(c->timerEvents[2 * (size_t)pair + 1], stream);
   }
 };
 
@@ -1439,7 +1454,7 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   if ((size_t)c->spillCap * blocks * kBlock > c->spill.n)
     return RTHIP_E_LIMIT;
   hipStream_t stream = sideStream ? c->stream2 : c->stream;
-  KernelTimer kt(c, isClosest(MODE) ? 1 : 3); // (the side stream is only used when kernel timing is off)
+  KernelTimer kt(c, isClosest(MODE) ? 1 : 3, stream);
   if (c->countWork)
     hipLaunchKernelGGL((k_trace<MODE, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
   else
@@ -1496,7 +1511,7 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, hipEvent_t acc
     // A depth's shadow launch (reads rayO, writes mask) and closest-hit launch (reads rayO/rayD, writes hit) are
     // independent, and each ends in a tail where a few long rays keep a few waves busy.  On two streams the second
     // launch's blocks move in as the first one's run dry, so one tail per depth is hidden; shade(d) joins both.
-    const bool side = d > 0 && !last && haveDirLights && c->overlapShadow && !c->kernelTiming;
+    const bool side = d > 0 && !last && haveDirLights && c->overlapShadow;
     if (side)
     {
       HIPCHK(hipEventRecord(c->evFork, c->stream));
@@ -1590,7 +1605,7 @@ int renderPasses(rthip_ctx* c, uint32_t sampBegin, uint32_t count, bool sync)
   // (more pieces measured slower: 3 -> -13 %, 8 -> -33 %) that alternate between the slots.  Nothing joins the slots at
   // the end of the call: the next frame's first piece starts while this frame's second piece is still shading, and
   // only the accumulate kernels are chained (per-pixel sums stay in sample order).
-  const bool pipelined = c->pipelineBatches && c->maxDepth == 1 && c->aovDepths == 0 && !c->kernelTiming && count >= 2;
+  const bool pipelined = c->pipelineBatches && c->maxDepth == 1 && c->aovDepths == 0 && count >= 2;
   uint32_t piece = c->batchCap;
   if (pipelined)
   {
@@ -1715,6 +1730,8 @@ int rthip_destroy(rthip_ctx* c)
   c->anyOut.release(), c->acc.release(), c->img.release(), c->rowScratch.release(), c->aovTri.release(), c->aovShadow.release();
   c->spill.release(), c->spill2.release(), c->fetch.release(), c->listA.release(), c->listB.release(), c->totals.release();
   (void)hipEventDestroy(c->evA), (void)hipEventDestroy(c->evB), (void)hipEventDestroy(c->evK0), (void)hipEventDestroy(c->evK1);
+  for (hipEvent_t e : c->timerEvents)
+    (void)hipEventDestroy(e);
   (void)hipEventDestroy(c->evFork), (void)hipEventDestroy(c->evJoin), (void)hipEventDestroy(c->evDone), (void)hipEventDestroy(c->evFrame);
   (void)hipEventDestroy(c->alt.evFork), (void)hipEventDestroy(c->alt.evJoin), (void)hipEventDestroy(c->alt.evDone);
   (void)hipStreamDestroy(c->alt.stream), (void)hipStreamDestroy(c->alt.stream2);
@@ -1888,8 +1905,6 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
   c->frameParity ^= 1u; // the previous frame's second slot may still be reading its camera and folding its totals
   hipLaunchKernelGGL(k_camera, dim3(1), dim3(64), 0, c->stream, *camera, frameCamera(c), frameTotals(c));
   HIPCHK(hipGetLastError());
-  std::memset(c->kernelMs, 0, sizeof(c->kernelMs));
-  std::memset(c->kernelLaunches, 0, sizeof(c->kernelLaunches));
   c->renderedAny = false;
   c->haveFrame = true;
   return 0;
@@ -2143,6 +2158,16 @@ int rthip_set_kernel_timing(rthip_ctx* c, int enabled)
   if (!c)
     return RTHIP_E_ARG;
   c->kernelTiming = enabled != 0;
+  if (enabled) // a fresh measurement: times and launch counts accumulate from here until they are switched on again
+  {
+    HIPCHK(hipSetDevice(c->device));
+    if (int rc = joinSlots(c))
+      return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->timerLog.clear();
+    std::memset(c->kernelMs, 0, sizeof(c->kernelMs));
+    std::memset(c->kernelLaunches, 0, sizeof(c->kernelLaunches));
+  }
   return 0;
 }
 
@@ -2150,6 +2175,23 @@ int rthip_get_kernel_times(rthip_ctx* c, float msOut[6], uint32_t launchesOut[6]
 {
   if (!c || !msOut || !launchesOut)
     return RTHIP_E_ARG;
+  if (!c->timerLog.empty())
+  {
+    HIPCHK(hipSetDevice(c->device));
+    if (int rc = joinSlots(c))
+      return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream2));
+    HIPCHK(hipStreamSynchronize(c->alt.stream));
+    HIPCHK(hipStreamSynchronize(c->alt.stream2));
+    for (size_t k = 0; k < c->timerLog.size(); ++k)
+    {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, c->timerEvents[2 * k], c->timerEvents[2 * k + 1]) == hipSuccess)
+        c->kernelMs[c->timerLog[k]] += ms;
+    }
+    c->timerLog.clear();
+  }
   for (int i = 0; i < 6; ++i)
   {
     msOut[i] = c->kernelMs[i];
