@@ -11,7 +11,7 @@ for WL in cube soup1m; do
   D=gpurun_out/kt_${TAG}_${WL}
   timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --workload $WL --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_${WL}_kt.log 2>&1 || { echo "kernel trace $WL failed"; tail -5 gpurun_out/${TAG}_${WL}_kt.log; exit 1; }
   cp "$(find $D -name '*kernel_stats.csv' | head -1)" profiles/${TAG}_${WL}_kernel_stats.csv || exit 1
-  tail -1 gpurun_out/${TAG}_${WL}_kt.log > profiles/${TAG}_${WL}_bench_under_rocprof.json
+  grep "^{\"metric\"" gpurun_out/${TAG}_${WL}_kt.log | tail -n 1 > profiles/${TAG}_${WL}_bench_under_rocprof.json
 done
 timeout -k 10 300 python3 bench.py > profiles/${TAG}_cube_bench.json 2> gpurun_out/${TAG}_cube_bench.err || { echo "bench cube failed"; tail -5 gpurun_out/${TAG}_cube_bench.err; exit 1; }
 timeout -k 10 300 python3 bench.py --workload soup1m > profiles/${TAG}_soup1m_bench.json 2> gpurun_out/${TAG}_soup1m_bench.err || { echo "bench soup failed"; exit 1; }
