@@ -325,3 +325,33 @@ def test_pipelined_batches_match_oracle_and_the_unpipelined_path(name, N):
         r.close()
     assert np.array_equal(accs[1].view(np.uint32), accs[0].view(np.uint32))
     assert np.array_equal(accs[1].view(np.uint32), want["accumulator"].view(np.uint32))
+
+
+def test_error_codes_of_the_kernel_abi():
+    """Every rthip_* call reports misuse with a code instead of rendering something else: camera outside the region the BVH
+    padding was sized for, passes outside the frame, calls before a frame exists, sizes beyond the compiled-in limits."""
+    import ctypes as C
+    spec = scenes.cube_scene()
+    r = spec.build_product(options=dict(maxDepth=2))
+    hl, ctx = ra.capi.hip_lib(), r.context
+    assert hl.rthip_enqueue_passes(ctx, 0, 1) == ra.capi.RTHIP_E_STATE          # no rthip_begin yet
+    acc = np.zeros((8, 8, 3), np.float32)
+    assert hl.rthip_read_accumulator(ctx, acc.ctypes.data_as(C.POINTER(C.c_float))) == ra.capi.RTHIP_E_STATE
+    far = ra.make_camera(position=(500.0, 0.0, 0.0), target=(0, 0, 0), S_O=6, f=0, A=0)
+    with pytest.raises(ra.RtError) as e:
+        r.begin_frame(far, 64, 64, 1)
+    assert e.value.code == ra.capi.RTHIP_E_BOUNDS and "origin bound" in str(e.value)
+    with pytest.raises(ra.RtError) as e:
+        r.begin_frame(spec.product_camera(), 70000, 64, 1)                        # tile origins are packed in 16 bits
+    assert e.value.code == ra.capi.RTHIP_E_ARG
+    r.begin_frame(spec.product_camera(), 64, 64, 2)
+    assert hl.rthip_enqueue_passes(ctx, 1, 2) == ra.capi.RTHIP_E_ARG             # passes [1,3) of a 2-sample frame
+    assert hl.rthip_enqueue_passes(ctx, 0, 0) == ra.capi.RTHIP_E_ARG
+    assert hl.rthip_enqueue_passes(None, 0, 1) == ra.capi.RTHIP_E_ARG
+    r.render_passes(0, 2)                                                         # the context still works afterwards
+    assert r.accumulator().any()
+    with pytest.raises(ra.RtError) as e:
+        r.set_option("maxDepth", 1000)
+        r.begin_frame(spec.product_camera(), 64, 64, 1)
+    assert e.value.code == ra.capi.RTHIP_E_LIMIT
+    r.close()
