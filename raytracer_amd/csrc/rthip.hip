@@ -1,20 +1,26 @@
 // rthip.hip -- hand-written gfx950 (CDNA4, wave64) kernels and the C ABI of include/rthip.h.
 //
 // Pipeline of one launch batch (S sample passes x P pixels = S*P paths, slot == path index, nothing moves):
-//   k_generate                      ray generation                       src/cpu/CPURenderer.cpp:158-192
-//   for depth d = 0 .. maxDepth-1
-//     k_trace<SHADOW>  (d > 0)      any-hit toward every directional light from the hit found at depth d-1
-//                                                                        src/cpu/CPUScene.cpp:31-38,107-121,139-186
-//     k_trace<CLOSEST>              closest hit of the depth-d ray       src/cpu/CPUScene.cpp:8,123-137,187-252
-//     k_shade                       fold the lights of depth d-1, roulette, hit set-up, bounce ray
-//                                                                        src/cpu/CPUScene.cpp:10-62
-//   k_trace<SHADOW>, k_shade(final) lights of the last hit
-//   k_accumulate                    accumulator += radiance / N in sample order   src/cpu/CPURenderer.cpp:196-197
+//   k_trace<PRIMARY / PRIMARY_GROUP>  depth 0: ray generation fused in (src/cpu/CPURenderer.cpp:158-192; k_generate +
+//                                     k_trace<CLOSEST> when fusion is switched off), closest hit
+//   k_shade(0)                        hit set-up, bounce ray                 src/cpu/CPUScene.cpp:10-62
+//   for depth d = 1 .. maxDepth-1
+//     k_trace<SHADOW>                 any-hit toward every directional light from the hit found at depth d-1
+//                                                                          src/cpu/CPUScene.cpp:31-38,107-121,139-186
+//     k_trace<CLOSEST>                closest hit of the depth-d ray (side by side with the shadow launch, two streams)
+//                                                                          src/cpu/CPUScene.cpp:8,123-137,187-252
+//     k_shade(d)                      fold the lights of depth d-1, roulette, hit set-up, bounce ray
+//   k_trace<SHADOW> (d = maxDepth)    shadow rays of the last hits, lights folded in the same launch (foldLights);
+//                                     k_shade(final) does the fold when there are no directional lights
+//   k_accumulate                      accumulator += radiance / N in sample order   src/cpu/CPURenderer.cpp:196-197
+//   k_fold_counters                   batch tallies -> frame totals (device memory; a frame needs no host round trip)
 //
-// Traversal kernels are persistent: a fixed grid of waves pulls 512-slot chunks with one atomic each, scans
-// the chunk's liveness bytes, compacts the live slots into a per-wave LDS list with ballot + mbcnt, and keeps
-// its 64 lanes busy by handing the next list entries to lanes whose ray has finished.  Each lane walks the
-// triangle BVH with a short stack in LDS (slot-major, conflict free) that spills to global memory when deeper.
+// Traversal kernels (one body, five template modes) run on a persistent grid: a wave pulls chunks of slots from one of eight
+// work counters, scans the chunk's liveness bytes, compacts the live slots into a per-wave LDS list with ballot + mbcnt, and
+// keeps its 64 lanes busy by handing the next list entries to lanes whose ray has finished.  Each lane walks the quantised
+// 4-wide triangle BVH with a short stack in LDS (slot-major, conflict free) that spills to global memory when deeper; leaves
+// are parked and tested in separate wave steps.  With a depth cap of 1 two batches are in flight on two sets of buffers
+// (rthip_ctx::Slot).  DESIGN.md section 5 has the measurements behind each of these choices.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
