@@ -66,7 +66,7 @@ def test_probe_bounce_bitexact(probe):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-@pytest.mark.parametrize("name,W,H,N,depth", [("cube", 256, 192, 4, 12), ("cube", 250, 130, 2, 1), ("bunny", 160, 160, 2, 4),
+@pytest.mark.parametrize("name,W,H,N,depth", [("cube", 256, 192, 4, 12), ("cube", 250, 130, 2, 1), ("cube", 512, 512, 1, 1), ("bunny", 160, 160, 2, 4),
                                              ("soup", 200, 200, 2, 6), ("hf", 192, 128, 2, 5), ("multi", 192, 160, 2, 6),
                                              ("box_glb", 200, 150, 3, 8), ("town_hall", 200, 150, 3, 8)])
 def test_render_matches_oracle_bitexact(name, W, H, N, depth):

@@ -251,3 +251,21 @@ def test_golden_bunny_and_multi_model():
     assert np.array_equal(topo, g["topo"]) and np.array_equal(model_of, g["model_of"]) and np.array_equal(boxes, g["boxes"])
     r = o.render(spec.oracle_camera(), 96, 80, 2, max_depth=6, aov_depths=2, workers=6)
     assert np.array_equal(r["tri_id"], g["tri_id"]) and np.array_equal(r["accumulator"].view(np.uint32), g["accumulator"].view(np.uint32))
+
+
+def test_config1_cpu_threadpool_render_is_deterministic():
+    """BASELINE configs[0]: the reference's scene at 512x512, 1 spp, primary rays + direct shading, on the restated
+    ThreadPool path (column tasks, oracle/column_pool.*).  The frame must not depend on the number of workers, and its
+    counts are the ones a GPU run of the same configuration has to reproduce (tests/test_gpu_parity.py)."""
+    spec = scenes.cube_scene()
+    o = spec.build_oracle()
+    a = o.render(spec.oracle_camera(), 512, 512, 1, max_depth=1, workers=6, aov_depths=1)
+    b = o.render(spec.oracle_camera(), 512, 512, 1, max_depth=1, workers=1, aov_depths=1)
+    assert np.array_equal(a["accumulator"].view(np.uint32), b["accumulator"].view(np.uint32))
+    assert np.array_equal(a["tri_id"], b["tri_id"]) and np.array_equal(a["shadow"], b["shadow"])
+    c = a["counters"]
+    assert c["extendPrimary"] == 512 * 512 and c["shadow"] == c["hits"][0] and 0 < c["hits"][0] < 512 * 512
+    assert c["nonFiniteAccepts"] == 0
+    # direct light only: a lit pixel is albedo (0,1,0) * n.l + ambient 0.03, a shadowed or missed one at most 0.03 (BRDF.cpp:4-14)
+    hit = a["tri_id"][0, 0] != 0xFFFFFFFF
+    assert np.all(a["accumulator"][~hit] == 0) and np.all(a["accumulator"][hit][:, 0] <= np.float32(0.03))
