@@ -1,0 +1,363 @@
+// rt_shade.h: frame set-up, shading, compaction, accumulation, tonemap / untile and the counter fold -- part of the gfx950 kernel library (see rthip.hip for the pipeline overview and DESIGN.md section 5).
+#pragma once
+#include "rt_kernel_common.h"
+
+namespace rtk
+{
+// ------------------------------------------------------------------------------------------------ set-up kernels
+// also clears the frame's counter totals (one dispatch less in the frame prologue)
+__global__ void k_camera(rthip_camera cam, CameraConsts* out, rthip_counters* totals)
+{
+  if (totals && blockIdx.x == 0)
+    for (uint32_t i = threadIdx.x; i < sizeof(rthip_counters) / sizeof(uint64_t); i += blockDim.x)
+      reinterpret_cast<uint64_t*>(totals)[i] = 0;
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    *out = rtd::cameraSetup(cam);
+}
+
+// stand-alone ray generation (used when primary-ray fusion is switched off, and as the A/B baseline for it)
+__global__ __launch_bounds__(kBlock) void k_generate(FrameGeom g, const CameraConsts* camp, PathBuffers pb, uint32_t sampBegin,
+                                                     uint32_t numPaths)
+{
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= numPaths)
+    return;
+  uint32_t s, i, w, h;
+  sampleOf(g, p, s, i);
+  if (!pixelOf(g, i, w, h))
+  {
+    pb.live[p] = kDeadZero;
+    return;
+  }
+  const CameraConsts k = *camp;
+  const uint32_t samp = sampBegin + s;
+  const vec3 rnd = rtd::rand01(w, h, samp);
+  vec3 o, d;
+  rtd::primaryRay(k, g.width, g.height, w, h, samp, rnd, o, d);
+  pb.rayO[p] = make_float4(o.x, o.y, o.z, 0.0f);
+  pb.rayD[p] = make_float4(d.x, d.y, d.z, 0.0f);
+  pb.live[p] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ shading
+struct ShadeArgs
+{
+  FrameGeom g;
+  DeviceScene scene;
+  PathBuffers pb;
+  const Lights* lights;
+  const CameraConsts* cam;
+  DeviceCounters* counters;
+  uint32_t numSlots, depth, maxDepth, sampBegin;
+  uint32_t finalFold;      // 1: only fold the pending lights and finish every path (depth == maxDepth)
+  uint32_t primaryInRegs;  // 1: depth-0 rays were never stored; recompute them from (pixel, sample)
+  uint32_t aovDepths;
+  uint32_t* aovTri;        // [S][aovDepths][P]
+  uint8_t* aovShadow;      // [S][aovDepths][P]
+  const uint32_t* list;    // sparse mode: slots alive at `depth` (nullptr = dense)
+  uint32_t* listNext;      // sparse mode: survivors are appended here (count in counters->listCount[depth+1])
+};
+
+template <bool SPARSE>
+__global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
+{
+  __shared__ uint32_t sAlive[kWavesPerBlock], sHits[kWavesPerBlock];
+  uint32_t nAlive = 0, nHits = 0;
+  const uint8_t depthTag = (uint8_t)a.depth;
+  const vec3 albedo{0.0f, 1.0f, 0.0f};    // CPUScene.cpp:245
+  const vec3 emissive{0.0f, 0.0f, 0.0f};  // CPUScene.cpp:246
+  const uint32_t total = SPARSE ? a.counters->listCount[a.depth] : a.numSlots;
+  // every wave runs the same number of iterations so that the sparse append can use wave-wide ballots
+  const uint32_t stride = gridDim.x * kBlock;
+  const uint32_t iters = (total + stride - 1) / stride;
+  for (uint32_t it = 0; it < iters; ++it)
+  {
+    const uint32_t item = it * stride + blockIdx.x * kBlock + threadIdx.x;
+    bool mine = item < total;
+    uint32_t p = item;
+    if (SPARSE)
+    {
+      if (mine)
+        p = a.list[item];
+    }
+    else if (mine)
+      mine = a.pb.live[p] == depthTag; // (the fused primary kernels write the depth-0 bytes: 0 = hit, kDeadZero = miss)
+    bool survives = false;
+    if (mine)
+    {
+      uint32_t s, i;
+      sampleOf(a.g, p, s, i);
+      uint32_t w = 0, h = 0;
+      const bool regen = a.depth == 0 && a.primaryInRegs;
+      const bool folding = a.finalFold != 0;
+      vec3 o{0, 0, 0}, d{0, 0, 1}, rnd{0, 0, 0};
+      vec3 radiance{0.0f, 0.0f, 0.0f}, material{1.0f, 1.0f, 1.0f}; // Ray.h:7-8
+      if (!regen)
+      {
+        const float4 ro = a.pb.rayO[p];
+        o = vec3{ro.x, ro.y, ro.z};
+        if (!folding)
+        {
+          const float4 rd = a.pb.rayD[p];
+          d = vec3{rd.x, rd.y, rd.z};
+          if (a.depth > 0)
+            material.x = rd.w;
+        }
+        if (a.depth > 0)
+        {
+          const float4 s0 = a.pb.s0[p];
+          radiance = vec3{s0.x, s0.y, s0.z};
+          if (!folding)
+          {
+            const float2 s1 = a.pb.s1[p];
+            material.y = s1.x, material.z = s1.y;
+          }
+          // lights of the previous hit, whose position is this ray's origin (CPUScene.cpp:31-49)
+          const uint32_t occl = a.lights->numDir ? a.pb.mask[p] : 0u;
+          radiance = foldLights(a.lights, occl, o, vec3{ro.w, s0.w, a.pb.nz[p]}, radiance);
+          if (a.depth - 1 < a.aovDepths)
+            a.aovShadow[((size_t)s * a.aovDepths + (a.depth - 1)) * a.g.numLocalPixels + i] = (uint8_t)occl;
+        }
+      }
+      bool finished = folding;
+      uint32_t rec = RTFLAT_INVALID;
+      float t = FLT_MAX;
+      if (!finished)
+      {
+        const uint2 hv = a.pb.hit[p];
+        t = __uint_as_float(hv.x);
+        rec = hv.y;
+        if (!(t < FLT_MAX)) // CPUScene.cpp:10
+          finished = true;
+        else
+        {
+          nHits++;
+          pixelOf(a.g, i, w, h);
+          rnd = rtd::rand01(w, h, a.sampBegin + s);
+          if (regen) // the primary ray was never stored: same function, same bits (only paths that hit need it)
+            rtd::primaryRay(*a.cam, a.g.width, a.g.height, w, h, a.sampBegin + s, rnd, o, d);
+          const float pr = rt::maxRef(rt::maxRef(albedo.x, albedo.y), albedo.z); // :13
+          if (a.depth > 5)                                                      // :19 (depth >= maxDepth never reaches here)
+          {
+            if (rnd.z >= pr)
+              finished = true;
+            else
+              material = material / pr;
+          }
+        }
+      }
+      if (finished)
+      {
+        if (a.depth == 0)
+          a.pb.live[p] = kDeadZero; // a primary miss adds exactly +0 to the accumulator: nothing to store
+        else
+        {
+          a.pb.s0[p] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+          a.pb.live[p] = kDead;
+        }
+      }
+      else
+      {
+        const float4* tp = reinterpret_cast<const float4*>(a.scene.tris + rec);
+        const float4 a2 = tp[2], a3 = tp[3];
+        const vec3 n{a2.y, a2.z, a2.w};
+        if (a.depth < a.aovDepths)
+          a.aovTri[((size_t)s * a.aovDepths + a.depth) * a.g.numLocalPixels + i] = __float_as_uint(a3.x);
+        const float payloadEmissive = a.depth == 0 ? 1.0f : 0.0f;                  // Ray.h:10, CPUScene.cpp:61
+        radiance = radiance + material * emissive * payloadEmissive;              // :27
+        material = material * albedo;                                             // :28
+        const vec3 position = o + d * t;                                          // :238
+        a.pb.rayO[p] = make_float4(position.x, position.y, position.z, n.x);
+        a.pb.s0[p] = make_float4(radiance.x, radiance.y, radiance.z, n.y);
+        a.pb.nz[p] = n.z;
+        if (a.depth + 1 < a.maxDepth) // the last shaded depth traces no bounce ray: neither direction nor throughput is kept
+        {
+          const vec3 normalLight = rt::dot(n, d) < 0 ? n : -n;                    // :240
+          const vec3 nd = rtd::bounceDirection(normalLight, rnd);                 // :54-60
+          a.pb.rayD[p] = make_float4(nd.x, nd.y, nd.z, material.x);
+          a.pb.s1[p] = make_float2(material.y, material.z);
+        }
+        a.pb.live[p] = (uint8_t)(a.depth + 1);
+        nAlive++;
+        survives = true;
+      }
+    }
+    if (SPARSE)
+    {
+      // append the survivors to the next depth's slot list: one atomic per wave, ranks from the ballot
+      const uint64_t m = __ballot(survives);
+      if (m)
+      {
+        uint32_t base = 0;
+        if (laneId() == (uint32_t)__ffsll((long long)m) - 1)
+          base = atomicAdd(&a.counters->listCount[a.depth + 1], (uint32_t)__popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1);
+        if (survives)
+          a.listNext[base + rankIn(m)] = p;
+      }
+    }
+  }
+  // block tallies: one atomic per block and counter
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    nAlive += __shfl_down(nAlive, off);
+    nHits += __shfl_down(nHits, off);
+  }
+  const uint32_t wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63u) == 0)
+  {
+    sAlive[wv] = nAlive;
+    sHits[wv] = nHits;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    uint32_t ta = 0, th = 0;
+    for (uint32_t k = 0; k < kWavesPerBlock; ++k)
+    {
+      ta += sAlive[k];
+      th += sHits[k];
+    }
+    if (ta)
+      atomicAdd(&a.counters->alive[a.depth + 1], (unsigned long long)ta);
+    if (th)
+      atomicAdd(&a.counters->hits[a.depth < 15 ? a.depth : 15], (unsigned long long)th);
+  }
+}
+
+// dense -> sparse hand-over: collects the slots alive at `depth` into a list (order: ascending slot within a
+// block's 4096-slot span, spans in arrival order).  One atomic per block.
+__global__ __launch_bounds__(kBlock) void k_compact(PathBuffers pb, uint32_t numSlots, uint32_t depth, uint32_t* list, uint32_t capacity,
+                                                    DeviceCounters* counters)
+{
+  __shared__ uint32_t sWave[kWavesPerBlock];
+  __shared__ uint32_t sBase;
+  const uint32_t lane = laneId(), wv = threadIdx.x >> 6;
+  const uint32_t spanBase = blockIdx.x * (kBlock * 16) + threadIdx.x * 16;
+  uint32_t bits = 0, cnt = 0;
+  if (spanBase < numSlots) // numSlots is a multiple of 64, the buffer is padded: the 16-byte load stays in bounds
+  {
+    const uint4 v = *reinterpret_cast<const uint4*>(pb.live + spanBase);
+    const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (spanBase + k < numSlots && ((wds[k >> 2] >> ((k & 3) * 8)) & 0xffu) == depth)
+      {
+        bits |= 1u << k;
+        cnt++;
+      }
+  }
+  // exclusive prefix of cnt over the wave, then over the block
+  uint32_t incl = cnt;
+  for (int off = 1; off < 64; off <<= 1)
+  {
+    const uint32_t up = __shfl_up(incl, off);
+    if ((int)lane >= off)
+      incl += up;
+  }
+  if (lane == 63)
+    sWave[wv] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    uint32_t tot = 0;
+    for (uint32_t k = 0; k < kWavesPerBlock; ++k)
+    {
+      const uint32_t c = sWave[k];
+      sWave[k] = tot;
+      tot += c;
+    }
+    sBase = tot ? atomicAdd(&counters->listCount[depth], tot) : 0u;
+  }
+  __syncthreads();
+  uint32_t dst = sBase + sWave[wv] + (incl - cnt);
+  for (int k = 0; k < 16; ++k)
+    if ((bits >> k) & 1u)
+    {
+      if (dst < capacity)
+        list[dst] = spanBase + k;
+      dst++;
+    }
+}
+
+// accumulator[pix] += radiance / float(N), sample passes in ascending order (CPURenderer.cpp:197)
+// `fresh` = first batch of a frame: the accumulator is taken as zero instead of being loaded (saves clearing it beforehand)
+__global__ __launch_bounds__(kBlock) void k_accumulate(FrameGeom g, PathBuffers pb, float* acc, uint32_t numBatchSamples, uint32_t fresh)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= g.numLocalPixels)
+    return;
+  float r = 0, gg = 0, b = 0;
+  bool loaded = fresh != 0; // 0 + x == x and 0 + 0 == +0: starting from zero is what the cleared accumulator would give
+  const float n = float(g.numSamples);
+  for (uint32_t s = 0; s < numBatchSamples; ++s)
+  {
+    const size_t p = (size_t)s * g.numLocalPixels + i;
+    // kDeadZero: the sample's radiance is exactly +0 (primary miss) -> adding 0/N leaves the sum unchanged
+    if (pb.live[p] != kDead)
+      continue;
+    if (!loaded)
+    {
+      r = acc[3 * (size_t)i], gg = acc[3 * (size_t)i + 1], b = acc[3 * (size_t)i + 2];
+      loaded = true;
+    }
+    const float4 v = pb.s0[p];
+    r += v.x / n;
+    gg += v.y / n;
+    b += v.z / n;
+  }
+  if (loaded)
+  {
+    acc[3 * (size_t)i] = r;
+    acc[3 * (size_t)i + 1] = gg;
+    acc[3 * (size_t)i + 2] = b;
+  }
+}
+
+// image = pow(max(accumulator * resolver, 0), 0.45)  (CPURenderer.cpp:196,198); display only
+__global__ __launch_bounds__(kBlock) void k_tonemap(const float* acc, float* img, uint32_t numFloats, float resolver)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < numFloats)
+    img[i] = powf(rt::maxRef(acc[i] * resolver, 0.0f), 0.45f);
+}
+
+// tile-major -> row-major scatter (multi-GPU assembly and read-back)
+__global__ __launch_bounds__(kBlock) void k_untile(FrameGeom g, const float* tileMajor, float* rowMajor, uint32_t numPixels)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= numPixels)
+    return;
+  uint32_t w, h;
+  if (!pixelOf(g, i, w, h))
+    return;
+  const size_t dst = 3 * ((size_t)h * g.width + w);
+  rowMajor[dst] = tileMajor[3 * (size_t)i];
+  rowMajor[dst + 1] = tileMajor[3 * (size_t)i + 1];
+  rowMajor[dst + 2] = tileMajor[3 * (size_t)i + 2];
+}
+
+// adds one batch's tallies to the frame totals (device memory), so a frame needs no host round trip between batches
+__global__ void k_fold_counters(const DeviceCounters* batch, rthip_counters* totals)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0)
+    return;
+  // atomics: two batches in flight on two streams may fold at the same time
+  auto add = [](uint64_t* dst, unsigned long long v) {
+    if (v)
+      atomicAdd(reinterpret_cast<unsigned long long*>(dst), v);
+  };
+  add(&totals->extendPrimary, batch->extendPrimary);
+  add(&totals->extendSecondary, batch->extendSecondary);
+  add(&totals->shadow, batch->shadow);
+  add(&totals->nodesVisited, batch->nodesVisited);
+  add(&totals->trisTested, batch->trisTested);
+  add(&totals->nonFiniteAccepts, batch->nonFinite);
+  add(&totals->nodesVisitedExtend, batch->nodesExtend);
+  add(&totals->trisTestedExtend, batch->trisExtend);
+  add(&totals->waveNodeSteps, batch->waveNodeSteps);
+  add(&totals->waveLeafSteps, batch->waveLeafSteps);
+  for (int i = 0; i < 16; ++i)
+    add(&totals->hits[i], batch->hits[i]);
+}
+} // namespace rtk

@@ -42,1150 +42,15 @@ using rtd::CameraConsts;
       return (int)e_;                                                                                                           \
   } while (0)
 
+#include "rt_kernel_common.h"
+#include "rt_probes.h"
+#include "rt_shade.h"
+#include "rt_trace.h"
+
+using namespace rtk;
+
 namespace
 {
-constexpr uint32_t kBlock = 256;       // 4 waves
-constexpr uint32_t kWavesPerBlock = kBlock / 64;
-constexpr uint32_t kChunk = 512;       // work items a wave scans and compacts at a time
-constexpr uint32_t kStackLds = 16;     // stack entries per lane kept in LDS
-constexpr uint32_t kMaxStack = 96;     // deepest triangle BVH accepted (LDS part + spill)
-constexpr uint32_t kLeafTrigger = 4;    // lanes that must be waiting on a leaf before a wave takes a leaf step (tuned on the 1M soup)
-constexpr uint32_t kDone = 0xffffffffu; // `cur`: the ray has no node, leaf or model left (== RTFLAT_INVALID)
-constexpr uint32_t kNone = 0xfffffffeu; // `cur` / `postponed`: empty
-constexpr uint32_t kRefillThreshold = 16; // refill once this many lanes are idle (or no lane is active)
-constexpr uint32_t kMaxRun = 1024;     // most work items one wave is handed (static mode)
-constexpr uint32_t kFetchShards = 8;   // one work counter per XCD label (blockIdx % 8): 8x the atomic rate of one word, L2-local ranges
-constexpr uint32_t kFetchStride = 64;  // counters 256 B apart
-constexpr uint32_t kMaxTraceLaunches = 2 * (64 + 2); // two traversal launches per depth, depth <= kMaxDepthSlots
-constexpr uint8_t kDead = 0xff;        // path finished, radiance in s0
-constexpr uint8_t kDeadZero = 0xfe;    // path finished with exactly zero radiance (primary miss) or pixel outside the image
-constexpr uint32_t kMaxLights = 8;
-constexpr size_t kMaxTimedLaunches = 16384; // event pairs kept by the kernel timer between two reads
-constexpr uint32_t kMaxDepthSlots = 64;
-
-enum TraceMode
-{
-  CLOSEST = 0,  // closest hit of the stored ray (depth >= 1, or depth 0 when primary rays are stored)
-  SHADOW = 1,   // any-hit toward every directional light from the stored origin
-  ANYPROBE = 2, // any-hit of the stored ray (probe entry point)
-  PRIMARY = 3,  // ray generation fused in (the primary ray is computed in registers, never stored); dynamic work fetch
-  PRIMARY_GROUP = 4 // the same for tiny scenes: static runs, one 8x8 pixel block at a time, no refilling
-};
-constexpr bool isPrimary(int mode) { return mode == PRIMARY || mode == PRIMARY_GROUP; }
-constexpr bool isClosest(int mode) { return mode == CLOSEST || isPrimary(mode); }
-
-struct DeviceScene
-{
-  const rtflat_model_node* modelNodes;
-  const rtflat_node* nodes;
-  const rtflat_tri* tris;
-  uint32_t numModelNodes;
-  float cullRel, cullAbs;
-};
-
-struct Lights
-{
-  rthip_dir_light dir[kMaxLights];
-  rthip_point_light point[kMaxLights];
-  uint32_t numDir, numPoint;
-};
-
-// device-side tallies; one 64-bit word each, updated once per wave/block at kernel end
-struct DeviceCounters
-{
-  unsigned long long extendPrimary, extendSecondary, shadow, nodesVisited, trisTested, nonFinite, nodesExtend, trisExtend;
-  unsigned long long waveNodeSteps, waveLeafSteps; // work counting: node / leaf steps executed by waves (x64 = lane slots offered)
-  unsigned long long hits[16];
-  unsigned long long alive[kMaxDepthSlots + 2]; // paths alive at each depth of the current batch
-  uint32_t listCount[kMaxDepthSlots + 2];       // sparse mode: entries of the slot list of each depth
-};
-
-struct FrameGeom
-{
-  uint32_t width, height, numSamples;
-  uint32_t tileSize, tilesX, numLocalTiles;
-  uint32_t numLocalPixels;  // P = numLocalTiles * tileSize^2
-  uint32_t tileShift;       // log2(tileSize); tiles are powers of two so that pixel decoding is shifts and masks
-  uint32_t sampleMagic;     // ceil(2^32 / numLocalTiles) (0 when numLocalTiles == 1): slot -> sample index without a division
-  const uint32_t* tileXY;   // device, numLocalTiles entries: x0 | y0 << 16, the tile's first pixel
-};
-
-struct PathBuffers
-{
-  // Between shade(d) and the light fold of depth d+1 a path needs its hit position, the hit's face normal and its
-  // radiance; only a path that goes on bouncing also needs a direction and its throughput ("material").  The arrays are
-  // split along that line, so the last shaded depth writes 36 bytes per hit instead of 64.
-  float4* rayO;  // o.xyz, w = face normal x of the hit the ray leaves from
-  float4* rayD;  // d.xyz, w = material.x                        (not written by the last shaded depth)
-  uint2* hit;    // x = float bits of t, y = triangle record index or RTFLAT_INVALID
-  float4* s0;    // radiance.xyz, w = face normal y of the previous hit
-  float2* s1;    // material.y, material.z                       (not written by the last shaded depth)
-  float* nz;     // face normal z of the previous hit
-  uint8_t* live; // depth at which the path is waiting, kDead / kDeadZero when finished
-  uint8_t* mask; // occlusion bits of the previous hit's shadow rays
-};
-
-__device__ __forceinline__ uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-__device__ __forceinline__ uint32_t rankIn(uint64_t m)
-{
-  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-// MI355X deals consecutive workgroups round-robin to its 8 XCDs (each with a private L2).  This bijective remap
-// hands every XCD one contiguous range of work instead, so neighbouring image regions -- which walk the same BVH
-// subtrees -- share an L2.  Performance only: nothing depends on where a block runs.
-__device__ __forceinline__ uint32_t xcdRemap(uint32_t b, uint32_t nb)
-{
-  const uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u, i = b >> 3;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-}
-
-// slot -> (sample index within the batch, local pixel index)
-__device__ __forceinline__ void sampleOf(const FrameGeom& g, uint32_t slot, uint32_t& s, uint32_t& i)
-{
-  const uint32_t t = slot >> (2u * g.tileShift); // global tile slot = s * numLocalTiles + local tile
-  s = g.sampleMagic ? __umulhi(t, g.sampleMagic) : t;
-  i = slot - s * g.numLocalPixels;
-}
-
-// local pixel index -> image pixel; 8x8 pixel blocks are contiguous so a wave covers a compact footprint
-__device__ __forceinline__ bool pixelOf(const FrameGeom& g, uint32_t i, uint32_t& w, uint32_t& h)
-{
-  const uint32_t sh = g.tileShift;
-  const uint32_t lt = i >> (2u * sh), k = i & ((1u << (2u * sh)) - 1u);
-  const uint32_t xy = g.tileXY[lt];
-  const uint32_t blk = k >> 6, l = k & 63u;
-  const uint32_t by = blk >> (sh - 3u), bx = blk & ((1u << (sh - 3u)) - 1u);
-  w = (xy & 0xffffu) + bx * 8u + (l & 7u);
-  h = (xy >> 16) + by * 8u + (l >> 3);
-  return w < g.width && h < g.height;
-}
-
-// Adds the direct light of the hit a path has just left (CPUScene.cpp:31-49, lights in that order): directional lights
-// unless their shadow ray was occluded, then the point lights, unshadowed.  `o` is the hit position, nPrev its face normal.
-// One function for k_shade and the shadow kernel's final fold, so both produce the same bits.
-__device__ __forceinline__ vec3 foldLights(const Lights* lights, uint32_t occluded, vec3 o, vec3 nPrev, vec3 radiance)
-{
-  const vec3 albedo{0.0f, 1.0f, 0.0f}; // CPUScene.cpp:245
-  for (uint32_t l = 0; l < lights->numDir; ++l)
-  {
-    const rthip_dir_light& L = lights->dir[l];
-    if (!((occluded >> l) & 1u))
-      radiance = radiance + rtd::brdfEvaluate(albedo, nPrev, vec3{-L.direction[0], -L.direction[1], -L.direction[2]},
-                                              vec3{L.color[0], L.color[1], L.color[2]});
-  }
-  for (uint32_t l = 0; l < lights->numPoint; ++l)
-  {
-    const rthip_point_light& L = lights->point[l];
-    const vec3 lightDir = vec3{L.position[0], L.position[1], L.position[2]} - o;
-    const float dist = rt::length(lightDir);
-    const float illuminance = rt::maxRef(1 - dist / L.attenuation, 0.0f);
-    radiance = radiance + illuminance * rtd::brdfEvaluate(albedo, nPrev, lightDir, vec3{L.color[0], L.color[1], L.color[2]});
-  }
-  return radiance;
-}
-
-// ------------------------------------------------------------------------------------------------ set-up kernels
-// also clears the frame's counter totals (one dispatch less in the frame prologue)
-__global__ void k_camera(rthip_camera cam, CameraConsts* out, rthip_counters* totals)
-{
-  if (totals && blockIdx.x == 0)
-    for (uint32_t i = threadIdx.x; i < sizeof(rthip_counters) / sizeof(uint64_t); i += blockDim.x)
-      reinterpret_cast<uint64_t*>(totals)[i] = 0;
-  if (threadIdx.x == 0 && blockIdx.x == 0)
-    *out = rtd::cameraSetup(cam);
-}
-
-// stand-alone ray generation (used when primary-ray fusion is switched off, and as the A/B baseline for it)
-__global__ __launch_bounds__(kBlock) void k_generate(FrameGeom g, const CameraConsts* camp, PathBuffers pb, uint32_t sampBegin,
-                                                     uint32_t numPaths)
-{
-  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-  if (p >= numPaths)
-    return;
-  uint32_t s, i, w, h;
-  sampleOf(g, p, s, i);
-  if (!pixelOf(g, i, w, h))
-  {
-    pb.live[p] = kDeadZero;
-    return;
-  }
-  const CameraConsts k = *camp;
-  const uint32_t samp = sampBegin + s;
-  const vec3 rnd = rtd::rand01(w, h, samp);
-  vec3 o, d;
-  rtd::primaryRay(k, g.width, g.height, w, h, samp, rnd, o, d);
-  pb.rayO[p] = make_float4(o.x, o.y, o.z, 0.0f);
-  pb.rayD[p] = make_float4(d.x, d.y, d.z, 0.0f);
-  pb.live[p] = 0;
-}
-
-// ------------------------------------------------------------------------------------------------ traversal
-struct TraceArgs
-{
-  DeviceScene scene;
-  PathBuffers pb;
-  const Lights* lights;      // SHADOW only
-  FrameGeom geom;            // PRIMARY only
-  const CameraConsts* cam;   // PRIMARY only
-  uint32_t sampBegin;        // PRIMARY only
-  uint32_t numSlots;         // dense: S*P work items, item == slot
-  const uint32_t* list;      // sparse: work item -> slot; nullptr in dense mode
-  const uint32_t* listCount; // sparse: number of work items (device memory)
-  uint32_t runLen;           // static mode: work items per wave (multiple of 64, <= kMaxRun)
-  uint32_t chunkLen;         // dynamic mode: work items per fetch (multiple of 64)
-  uint32_t refillAt;         // idle lanes that trigger a refill from the work list
-  uint32_t leafTrigger;      // lanes waiting on a leaf that trigger a leaf step
-  uint32_t stealSpans;       // spans a wave may pull chunks from: its own first, then its neighbours'
-  uint32_t* fetch;           // dynamic mode: kFetchShards counters, kFetchStride words apart, zeroed before the launch
-  uint32_t depth;            // live[] value this launch serves (dense mode filter)
-  uint32_t* spill;           // [spillCap][gridLanes]
-  DeviceCounters* counters;
-  float tmin, tmax;
-  uint8_t* anyOut;           // ANYPROBE
-  uint32_t foldFinal;        // SHADOW: 1 = this is the last depth: fold the lights into the radiance and finish the path here
-  uint32_t aovDepths;        // SHADOW with foldFinal: shadow-flag AOV
-  uint8_t* aovShadow;
-};
-
-template <int MODE, bool COUNT>
-__global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs a)
-{
-  __shared__ uint32_t sStack[kWavesPerBlock][kStackLds][64];
-  __shared__ uint32_t sList[kWavesPerBlock][kChunk];
-
-  const uint32_t lane = laneId();
-  const uint32_t wv = threadIdx.x >> 6;
-  uint32_t(*stack)[64] = sStack[wv];
-  uint32_t* list = sList[wv];
-  const uint32_t gridLanes = gridDim.x * kBlock;
-  uint32_t* spill = a.spill + (blockIdx.x * kBlock + threadIdx.x);
-
-  const rtflat_model_node* __restrict__ modelNodes = a.scene.modelNodes;
-  const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(a.scene.nodes);
-  const float4* __restrict__ tris4 = reinterpret_cast<const float4*>(a.scene.tris);
-  const uint32_t numModelNodes = a.scene.numModelNodes;
-
-  // work distribution
-  //  static mode (chunkLen == 0): wave `wid` owns items [wid*runLen, (wid+1)*runLen) -- used for coherent primary rays
-  //    over tiny scenes, where every ray costs the same and 64-slot groups need no refilling;
-  //  dynamic mode: a persistent grid; the items are split into kFetchShards contiguous spans (one per XCD label, so that
-  //    an XCD's L2 keeps seeing the same image region) and a wave pulls chunkLen items at a time from its span's counter.
-  const bool sparse = a.list != nullptr;
-  const uint32_t total = sparse ? *a.listCount : a.numSlots;
-  constexpr bool dynamic = MODE != PRIMARY_GROUP;
-  const uint32_t wid = xcdRemap(blockIdx.x, gridDim.x) * kWavesPerBlock + wv;
-  uint32_t runNext = dynamic ? 0u : min(total, wid * a.runLen);
-  uint32_t runEnd = dynamic ? 0u : min(total, runNext + a.runLen);
-  const uint32_t shard = blockIdx.x % kFetchShards;
-  const uint32_t chunksPerShard = dynamic ? ((total + kFetchShards - 1) / kFetchShards + a.chunkLen - 1) / a.chunkLen : 0u;
-  bool exhausted = !dynamic; // dynamic mode: no more chunks anywhere
-  uint32_t shardsDone = 0;   // spans found empty so far: the wave's own first, then its neighbours' (work stealing)
-  // pulls the next chunk into [runNext, runEnd): from this wave's own span while it lasts, then from the other spans
-  // in turn (one attempt per call), so that an XCD whose image region was cheap helps the others out instead of idling
-  // through their tail.
-  auto fetchChunk = [&]() {
-    const uint32_t sh = (shard + shardsDone) % kFetchShards;
-    uint32_t c = 0;
-    if (lane == 0)
-      c = atomicAdd(a.fetch + sh * kFetchStride, 1u);
-    c = __builtin_amdgcn_readfirstlane(c);
-    const uint32_t base = (sh * chunksPerShard + c) * a.chunkLen;
-    if (c < chunksPerShard && base < total)
-    {
-      runNext = base;
-      runEnd = min(total, base + a.chunkLen);
-    }
-    else if (++shardsDone >= a.stealSpans) // this span is empty: the next call tries the next one
-      exhausted = true;
-  };
-
-  // wave-uniform work-list state
-  uint32_t listCount = 0, listNext = 0;
-
-  // per-lane ray state
-  bool active = false;
-  bool groupValid = false; // PRIMARY: this lane carries a camera sample of the current group
-  uint32_t slot = 0;
-  vec3 o{0, 0, 0}, d{0, 0, 1}, invD{0, 0, 0}, oi{0, 0, 0};
-  float best = FLT_MAX, cull = FLT_MAX;
-  uint32_t bestRec = RTFLAT_INVALID;
-  uint32_t cur = kNone;          // inner node index, a second leaf waiting for the leaf step, kDone or kNone
-  uint32_t mk = 0;               // model-tree cursor (pre-order index)
-  uint32_t sp = 0, spLo = 0;     // stack entries [spLo, sp) are in LDS, [0, spLo) spilled
-  uint32_t postponed = 0xfffffffeu; // a leaf reference parked while the lane keeps walking inner nodes (kNone = none)
-  bool needPop = false;          // the lane needs a new `cur` from its stack / the model tree
-  uint32_t lightIdx = 0;         // SHADOW: which directional light this lane is testing
-  uint32_t occluded = 0;         // SHADOW: result bits
-  float prevNx = 0.0f;           // SHADOW: rayO.w, the face normal x of the hit the shadow rays leave from
-  uint32_t nRays = 0, nNodes = 0, nTris = 0, nNodeSteps = 0, nLeafSteps = 0;
-
-  // SHADOW: every light of this lane's path has been tested.  Normally the occlusion bits go to mask[] and the next
-  // shade launch folds the lights; at the last depth the fold happens right here (same function, same bits), which
-  // saves that launch and its re-read of the path state.
-  auto finishShadow = [&]() {
-    if (a.foldFinal)
-    {
-      const float4 s0 = a.pb.s0[slot];
-      const vec3 radiance = foldLights(a.lights, occluded, o, vec3{prevNx, s0.w, a.pb.nz[slot]}, vec3{s0.x, s0.y, s0.z});
-      if (a.depth - 1 < a.aovDepths)
-      {
-        uint32_t sidx, i;
-        sampleOf(a.geom, slot, sidx, i);
-        a.aovShadow[((size_t)sidx * a.aovDepths + (a.depth - 1)) * a.geom.numLocalPixels + i] = (uint8_t)occluded;
-      }
-      a.pb.s0[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-      a.pb.live[slot] = kDead;
-    }
-    else
-      a.pb.mask[slot] = (uint8_t)occluded;
-  };
-
-  for (;;)
-  {
-    if (MODE == PRIMARY_GROUP)
-    {
-      // ---------------- coherent primary rays over a tiny scene: take the run 64 slots (one 8x8 pixel block) at a time,
-      // generate the rays in registers at full occupancy, traverse until the whole group is done, store the 64 hit
-      // records together
-      if (__ballot(active) == 0)
-      {
-        // a primary miss contributes exactly +0: its slot is marked finished here and costs the shade kernel nothing
-        if (groupValid)
-        {
-          const bool hitSomething = bestRec != RTFLAT_INVALID;
-          if (hitSomething)
-            a.pb.hit[slot] = make_uint2(__float_as_uint(best), bestRec);
-          a.pb.live[slot] = hitSomething ? (uint8_t)0 : kDeadZero;
-        }
-        groupValid = false;
-        if (runNext >= runEnd)
-          break;
-        slot = runNext + lane;
-        runNext += 64;
-        uint32_t sidx, i, w, h;
-        sampleOf(a.geom, slot, sidx, i);
-        const bool inImage = pixelOf(a.geom, i, w, h);
-        if (slot < runEnd && !inImage)
-          a.pb.live[slot] = kDeadZero; // padding pixel of a tile that overhangs the image
-        if (slot < runEnd && inImage)
-        {
-          const uint32_t samp = a.sampBegin + sidx;
-          rtd::primaryRay(*a.cam, a.geom.width, a.geom.height, w, h, samp, rtd::rand01(w, h, samp), o, d);
-          invD = rtd::padInvDir(d);
-          oi = o * invD;
-          best = FLT_MAX;
-          cull = FLT_MAX;
-          bestRec = RTFLAT_INVALID;
-          cur = kNone;
-          postponed = kNone;
-          needPop = true;
-          mk = 0;
-          sp = spLo = 0;
-          active = true;
-          groupValid = true;
-          nRays++;
-        }
-        continue;
-      }
-    }
-    else if (MODE == PRIMARY)
-    {
-      // ---------------- primary rays over a real scene: neighbouring pixels still walk very different numbers of nodes,
-      // so idle lanes are refilled with the next consecutive slots of the chunk once half the wave is idle
-      const uint64_t idleMask = __ballot(!active);
-      const uint32_t numIdle = __popcll(idleMask);
-      if (numIdle >= 32)
-      {
-        if (runNext >= runEnd && !exhausted)
-          fetchChunk();
-        if (runNext < runEnd)
-        {
-          const uint32_t r = rankIn(idleMask);
-          const uint32_t avail = runEnd - runNext;
-          if (!active && r < avail)
-          {
-            slot = runNext + r;
-            uint32_t sidx, i, w, h;
-            sampleOf(a.geom, slot, sidx, i);
-            if (!pixelOf(a.geom, i, w, h))
-              a.pb.live[slot] = kDeadZero; // padding pixel of a tile that overhangs the image
-            else
-            {
-              const uint32_t samp = a.sampBegin + sidx;
-              rtd::primaryRay(*a.cam, a.geom.width, a.geom.height, w, h, samp, rtd::rand01(w, h, samp), o, d);
-              invD = rtd::padInvDir(d);
-              oi = o * invD;
-              best = FLT_MAX;
-              cull = FLT_MAX;
-              bestRec = RTFLAT_INVALID;
-              cur = kNone;
-              postponed = kNone;
-              needPop = true;
-              mk = 0;
-              sp = spLo = 0;
-              active = true;
-              nRays++;
-            }
-          }
-          runNext += min(numIdle, avail);
-        }
-      }
-      if (__ballot(active) == 0)
-      {
-        if (exhausted && runNext >= runEnd)
-          break;
-        continue;
-      }
-    }
-    else
-    {
-      // ---------------- work list: scan + compact the next chunk of the run when the list has run dry
-      const uint64_t idleMask = __ballot(!active);
-      const uint32_t numIdle = __popcll(idleMask);
-      if (listNext >= listCount && numIdle >= a.refillAt && runNext >= runEnd && !exhausted)
-        fetchChunk();
-      if (listNext >= listCount && runNext < runEnd && numIdle >= a.refillAt)
-      {
-        const uint32_t chunkEnd = min(runEnd, runNext + kChunk);
-        uint32_t n = 0;
-        for (uint32_t base = runNext; base < chunkEnd; base += 64)
-        {
-          const uint32_t item = base + lane;
-          bool isLive = item < chunkEnd;
-          uint32_t s = item;
-          if (sparse)
-          {
-            if (isLive)
-              s = a.list[item];
-          }
-          else
-            isLive = isLive && (a.pb.live[item] == (uint8_t)a.depth);
-          const uint64_t m = __ballot(isLive);
-          if (isLive)
-            list[n + rankIn(m)] = s;
-          n += __popcll(m);
-        }
-        runNext = chunkEnd;
-        listCount = n;
-        listNext = 0;
-        // the list is written and read by this wave only; LDS operations of one wave complete in order
-      }
-      // ---------------- hand list entries to idle lanes (ballot + mbcnt compaction)
-      const uint32_t avail = listCount - listNext;
-      if (avail > 0 && (numIdle >= a.refillAt || numIdle == 64))
-      {
-        const uint32_t r = rankIn(idleMask);
-        const bool take = !active && r < avail;
-        if (take)
-        {
-          slot = list[listNext + r];
-          const float4 ro = a.pb.rayO[slot];
-          o = vec3{ro.x, ro.y, ro.z};
-          if (MODE == SHADOW)
-          {
-            lightIdx = 0;
-            occluded = 0;
-            prevNx = ro.w;
-            const rthip_dir_light& L = a.lights->dir[0];
-            d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]}; // Ray(position, -d.direction), CPUScene.cpp:34
-          }
-          else
-          {
-            const float4 rd = a.pb.rayD[slot];
-            d = vec3{rd.x, rd.y, rd.z};
-          }
-          invD = rtd::padInvDir(d);
-          oi = o * invD;
-          best = FLT_MAX;
-          cull = FLT_MAX;
-          bestRec = RTFLAT_INVALID;
-          cur = kNone;
-          postponed = kNone;
-          needPop = true;
-          mk = 0;
-          sp = spLo = 0;
-          active = true;
-          nRays++;
-        }
-        listNext += min(numIdle, avail);
-      }
-      if (__ballot(active) == 0)
-      {
-        if (exhausted && runNext >= runEnd && listNext >= listCount)
-          break;
-        continue;
-      }
-    }
-
-    const bool refillPossible = (MODE == PRIMARY_GROUP) ? false
-                                : (MODE == PRIMARY)     ? (runNext < runEnd || !exhausted)
-                                                        : (listNext < listCount || runNext < runEnd || !exhausted);
-    const uint32_t refillAt = (MODE == PRIMARY) ? 32u : a.refillAt;
-    // ---------------- traversal: a wave alternates NODE steps (every lane that holds an inner node tests its two child
-    // boxes) with LEAF steps (every lane that holds a postponed leaf runs the reference's triangle test on it).  A lane
-    // that reaches a leaf parks it in `postponed` and keeps walking inner nodes; the leaf step is taken only once
-    // kLeafTrigger lanes cannot go on without it (they met a second leaf, or have nothing else left) or no lane can do a
-    // node step.  Compared with a plain while-while loop, where every lane waits at its leaf until the slowest lane has
-    // found one, this keeps most lanes busy in both kinds of step.
-    for (;;)
-    {
-      // --- resolve: lanes that need a new `cur` pop their stack, or walk on to the next model leaf when it is empty
-      while (active && needPop)
-      {
-        uint32_t got;
-        if (sp != 0)
-        {
-          if (sp == spLo)
-          {
-            spLo--;
-            stack[spLo % kStackLds][lane] = spill[(size_t)spLo * gridLanes];
-          }
-          sp--;
-          got = stack[sp % kStackLds][lane];
-        }
-        else
-        {
-          // stack empty: next model leaf whose box chain passes the reference's test, in DFS order
-          // (CPUScene.cpp:123-137 / 107-121: both children always, box test with the caller's tmin/tmax)
-          got = kDone;
-          while (mk < numModelNodes)
-          {
-            const rtflat_model_node* mn = modelNodes + mk;
-            if (COUNT)
-              nNodes++;
-            // AABB.h:49 divides by the direction: invD is that quotient unless it was clamped (axis-parallel rays, rare),
-            // so the three IEEE divisions are repeated only for a wave that holds such a ray
-            vec3 invRef = invD;
-            if (fabsf(invD.x) == 1e18f || fabsf(invD.y) == 1e18f || fabsf(invD.z) == 1e18f)
-              invRef = rt::rcp3(d);
-            if (!rtd::refSlab(mn->lo, mn->hi, o, invRef, a.tmin, a.tmax))
-            {
-              mk += mn->subtreeSize; // skip the subtree
-              continue;
-            }
-            mk++;
-            if (mn->triCount > 0)
-            {
-              got = mn->blas;
-              break;
-            }
-          }
-        }
-        if (got != kDone && (int)got < 0 && postponed == kNone)
-          postponed = got; // a leaf: park it and keep looking for inner-node work
-        else
-        {
-          cur = got;
-          needPop = false;
-        }
-      }
-      // --- rays that have nothing left
-      if (active && cur == kDone && postponed == kNone)
-      {
-        bool done = true;
-        if (MODE == SHADOW)
-        {
-          // not occluded for this light; the next light restarts the walk
-          lightIdx++;
-          if (lightIdx < a.lights->numDir)
-          {
-            const rthip_dir_light& L = a.lights->dir[lightIdx];
-            d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]};
-            invD = rtd::padInvDir(d);
-            oi = o * invD;
-            mk = 0;
-            needPop = true;
-            cur = kNone;
-            nRays++;
-            done = false;
-          }
-          else
-            finishShadow();
-        }
-        else if (MODE == CLOSEST)
-          a.pb.hit[slot] = make_uint2(__float_as_uint(best), bestRec);
-        else if (MODE == PRIMARY)
-        {
-          // a primary miss contributes exactly +0: its slot is marked finished here and costs the shade kernel nothing
-          const bool hitSomething = bestRec != RTFLAT_INVALID;
-          if (hitSomething)
-            a.pb.hit[slot] = make_uint2(__float_as_uint(best), bestRec);
-          a.pb.live[slot] = hitSomething ? (uint8_t)0 : kDeadZero;
-        }
-        else if (MODE == ANYPROBE)
-          a.anyOut[slot] = 0;
-        // PRIMARY_GROUP: the group's hit records are stored together once every lane has finished
-        if (done)
-          active = false;
-      }
-      const bool atNode = active && !needPop && (int)cur >= 0;
-      const bool stalled = active && !needPop && postponed != kNone && !((int)cur >= 0);
-      const uint64_t nodeMask = __ballot(atNode || (active && needPop));
-      const uint32_t numStalled = __popcll(__ballot(stalled));
-      const bool leafStep = numStalled >= a.leafTrigger || (nodeMask == 0 && numStalled > 0);
-      if (leafStep)
-      {
-        if (COUNT)
-          nLeafSteps++;
-        // --- LEAF step: the reference's triangle test on every record of every parked leaf
-        if (active && postponed != kNone)
-        {
-          const uint32_t first = rtflat_leaf_first(postponed), count = rtflat_leaf_count(postponed);
-          postponed = kNone;
-          bool anyAccepted = false;
-          for (uint32_t k = 0; k < count; ++k)
-          {
-            const float4* tp = tris4 + (size_t)(first + k) * 4;
-            const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
-            if (COUNT)
-              nTris++;
-            float t;
-            const int acc = rtd::triangleTest(vec3{a0.x, a0.y, a0.z}, vec3{a0.w, a1.x, a1.y}, vec3{a1.z, a1.w, a2.x}, o, d, a.tmin, a.tmax, t);
-            if (acc == 2)
-              atomicAdd(&a.counters->nonFinite, 1ull);
-            if (acc != 1)
-              continue;
-            if (isClosest(MODE))
-            {
-              bool better = t < best;
-              if (!better && t == best)
-              {
-                // tie: the triangle later in (DFS model order, index in model) wins (CPUScene.cpp:231, :136)
-                const uint32_t keyNew = a.scene.tris[first + k].orderKey, keyOld = a.scene.tris[bestRec].orderKey;
-                better = keyNew > keyOld;
-              }
-              if (better)
-              {
-                best = t;
-                bestRec = first + k;
-                cull = rt::fma(best, 1.0f + a.scene.cullRel, a.scene.cullAbs);
-              }
-            }
-            else
-            {
-              anyAccepted = true;
-              break;
-            }
-          }
-          if (!isClosest(MODE) && anyAccepted)
-          {
-            // first accepted triangle ends an any-hit ray (testModel returns true, CPUScene.cpp:182)
-            if (MODE == SHADOW)
-            {
-              occluded |= 1u << lightIdx;
-              lightIdx++;
-              if (lightIdx < a.lights->numDir)
-              {
-                const rthip_dir_light& L = a.lights->dir[lightIdx];
-                d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]};
-                invD = rtd::padInvDir(d);
-                oi = o * invD;
-                mk = 0;
-                sp = spLo = 0;
-                cur = kNone;
-                needPop = true;
-                nRays++;
-              }
-              else
-              {
-                finishShadow();
-                active = false;
-              }
-            }
-            else
-            {
-              a.anyOut[slot] = 1;
-              active = false;
-            }
-          }
-          else if (!needPop && cur != kDone && (int)cur < 0)
-          {
-            // the lane was holding a second leaf: park it now and look for more work
-            postponed = cur;
-            cur = kNone;
-            needPop = true;
-          }
-        }
-        continue;
-      }
-      if (nodeMask == 0)
-        break; // nothing left to traverse in this wave: back to the work list
-      // leave for a refill as soon as enough lanes are idle and there is work to hand out
-      if (refillPossible && (uint32_t)__popcll(__ballot(!active)) >= refillAt)
-        break;
-      // --- NODE step: one 64-byte node = four quantised child boxes
-      if (COUNT)
-        nNodeSteps++;
-      if (atNode)
-      {
-        const float4* np = nodes4 + (size_t)cur * 4;
-        const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-        if (COUNT)
-          nNodes++;
-        const rtd::WideNode wn = rtd::wideNodeSetup(w0, w2, w3, invD, oi);
-        float en0, ex0, en1, ex1, en2, ex2, en3, ex3;
-        rtd::wideSlabPair<0>(wn, en0, ex0, en1, ex1);
-        rtd::wideSlabPair<2>(wn, en2, ex2, en3, ex3);
-        constexpr bool kClosest = isClosest(MODE);
-        // sort the (at most four) children that were hit by entry distance; unused slots have inverted boxes
-        uint32_t k0 = ((en0 <= ex0) && (!kClosest || en0 <= cull)) ? __float_as_uint(en0) : 0xffffffffu;
-        uint32_t k1 = ((en1 <= ex1) && (!kClosest || en1 <= cull)) ? __float_as_uint(en1) : 0xffffffffu;
-        uint32_t k2 = ((en2 <= ex2) && (!kClosest || en2 <= cull)) ? __float_as_uint(en2) : 0xffffffffu;
-        uint32_t k3 = ((en3 <= ex3) && (!kClosest || en3 <= cull)) ? __float_as_uint(en3) : 0xffffffffu;
-        uint32_t r0 = __float_as_uint(w1.x), r1 = __float_as_uint(w1.y), r2 = __float_as_uint(w1.z), r3 = __float_as_uint(w1.w);
-        rtd::orderPair(k0, r0, k1, r1);
-        rtd::orderPair(k2, r2, k3, r3);
-        rtd::orderPair(k0, r0, k2, r2);
-        rtd::orderPair(k1, r1, k3, r3);
-        rtd::orderPair(k1, r1, k2, r2);
-        // push the farther ones, farthest first, so that the nearest of them is popped first.  Misses sort to the
-        // end, so the valid flags are monotone (v1 >= v2 >= v3) and the three references can be written without
-        // branches: r3 at sp, r2 at sp+v3, r1 at sp+v3+v2 -- a reference that is not valid is overwritten by the next
-        // one or lands above the new top.  One spill check per step makes room for all three.
-        if (sp + 3 - spLo > kStackLds)
-        {
-          do
-          {
-            spill[(size_t)spLo * gridLanes] = stack[spLo % kStackLds][lane];
-            spLo++;
-          } while (sp + 3 - spLo > kStackLds);
-        }
-        const uint32_t v3 = k3 != 0xffffffffu, v2 = k2 != 0xffffffffu, v1 = k1 != 0xffffffffu;
-        stack[sp % kStackLds][lane] = r3;
-        stack[(sp + v3) % kStackLds][lane] = r2;
-        stack[(sp + v3 + v2) % kStackLds][lane] = r1;
-        sp += v3 + v2 + v1;
-        if (k0 == 0xffffffffu)
-          needPop = true;
-        else if ((int)r0 < 0 && postponed == kNone)
-        {
-          postponed = r0; // a leaf: park it, go on with the stack
-          needPop = true;
-        }
-        else
-          cur = r0; // an inner node, or a second leaf (the lane now waits for the leaf step)
-        if (needPop)
-          cur = kNone;
-      }
-    }
-    // the wave is out of traversal work (or wants a refill): PRIMARY_GROUP and the list modes pick up from here
-  }
-
-  // ---------------- tallies: one atomic per wave and counter
-  for (int off = 32; off > 0; off >>= 1)
-  {
-    nRays += __shfl_down(nRays, off);
-    if (COUNT)
-    {
-      nNodes += __shfl_down(nNodes, off);
-      nTris += __shfl_down(nTris, off);
-    }
-  }
-  if (lane == 0)
-  {
-    if (nRays)
-    {
-      unsigned long long* dst =
-          (MODE == SHADOW) ? &a.counters->shadow : ((isPrimary(MODE) || a.depth == 0) ? &a.counters->extendPrimary : &a.counters->extendSecondary);
-      atomicAdd(dst, (unsigned long long)nRays);
-    }
-    if (COUNT)
-    {
-      atomicAdd(&a.counters->waveNodeSteps, (unsigned long long)nNodeSteps);
-      atomicAdd(&a.counters->waveLeafSteps, (unsigned long long)nLeafSteps);
-    }
-    if (COUNT && nNodes)
-    {
-      atomicAdd(&a.counters->nodesVisited, (unsigned long long)nNodes);
-      if (isClosest(MODE))
-        atomicAdd(&a.counters->nodesExtend, (unsigned long long)nNodes);
-    }
-    if (COUNT && nTris)
-    {
-      atomicAdd(&a.counters->trisTested, (unsigned long long)nTris);
-      if (isClosest(MODE))
-        atomicAdd(&a.counters->trisExtend, (unsigned long long)nTris);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ shading
-struct ShadeArgs
-{
-  FrameGeom g;
-  DeviceScene scene;
-  PathBuffers pb;
-  const Lights* lights;
-  const CameraConsts* cam;
-  DeviceCounters* counters;
-  uint32_t numSlots, depth, maxDepth, sampBegin;
-  uint32_t finalFold;      // 1: only fold the pending lights and finish every path (depth == maxDepth)
-  uint32_t primaryInRegs;  // 1: depth-0 rays were never stored; recompute them from (pixel, sample)
-  uint32_t aovDepths;
-  uint32_t* aovTri;        // [S][aovDepths][P]
-  uint8_t* aovShadow;      // [S][aovDepths][P]
-  const uint32_t* list;    // sparse mode: slots alive at `depth` (nullptr = dense)
-  uint32_t* listNext;      // sparse mode: survivors are appended here (count in counters->listCount[depth+1])
-};
-
-template <bool SPARSE>
-__global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
-{
-  __shared__ uint32_t sAlive[kWavesPerBlock], sHits[kWavesPerBlock];
-  uint32_t nAlive = 0, nHits = 0;
-  const uint8_t depthTag = (uint8_t)a.depth;
-  const vec3 albedo{0.0f, 1.0f, 0.0f};    // CPUScene.cpp:245
-  const vec3 emissive{0.0f, 0.0f, 0.0f};  // CPUScene.cpp:246
-  const uint32_t total = SPARSE ? a.counters->listCount[a.depth] : a.numSlots;
-  // every wave runs the same number of iterations so that the sparse append can use wave-wide ballots
-  const uint32_t stride = gridDim.x * kBlock;
-  const uint32_t iters = (total + stride - 1) / stride;
-  for (uint32_t it = 0; it < iters; ++it)
-  {
-    const uint32_t item = it * stride + blockIdx.x * kBlock + threadIdx.x;
-    bool mine = item < total;
-    uint32_t p = item;
-    if (SPARSE)
-    {
-      if (mine)
-        p = a.list[item];
-    }
-    else if (mine)
-      mine = a.pb.live[p] == depthTag; // (the fused primary kernels write the depth-0 bytes: 0 = hit, kDeadZero = miss)
-    bool survives = false;
-    if (mine)
-    {
-      uint32_t s, i;
-      sampleOf(a.g, p, s, i);
-      uint32_t w = 0, h = 0;
-      const bool regen = a.depth == 0 && a.primaryInRegs;
-      const bool folding = a.finalFold != 0;
-      vec3 o{0, 0, 0}, d{0, 0, 1}, rnd{0, 0, 0};
-      vec3 radiance{0.0f, 0.0f, 0.0f}, material{1.0f, 1.0f, 1.0f}; // Ray.h:7-8
-      if (!regen)
-      {
-        const float4 ro = a.pb.rayO[p];
-        o = vec3{ro.x, ro.y, ro.z};
-        if (!folding)
-        {
-          const float4 rd = a.pb.rayD[p];
-          d = vec3{rd.x, rd.y, rd.z};
-          if (a.depth > 0)
-            material.x = rd.w;
-        }
-        if (a.depth > 0)
-        {
-          const float4 s0 = a.pb.s0[p];
-          radiance = vec3{s0.x, s0.y, s0.z};
-          if (!folding)
-          {
-            const float2 s1 = a.pb.s1[p];
-            material.y = s1.x, material.z = s1.y;
-          }
-          // lights of the previous hit, whose position is this ray's origin (CPUScene.cpp:31-49)
-          const uint32_t occl = a.lights->numDir ? a.pb.mask[p] : 0u;
-          radiance = foldLights(a.lights, occl, o, vec3{ro.w, s0.w, a.pb.nz[p]}, radiance);
-          if (a.depth - 1 < a.aovDepths)
-            a.aovShadow[((size_t)s * a.aovDepths + (a.depth - 1)) * a.g.numLocalPixels + i] = (uint8_t)occl;
-        }
-      }
-      bool finished = folding;
-      uint32_t rec = RTFLAT_INVALID;
-      float t = FLT_MAX;
-      if (!finished)
-      {
-        const uint2 hv = a.pb.hit[p];
-        t = __uint_as_float(hv.x);
-        rec = hv.y;
-        if (!(t < FLT_MAX)) // CPUScene.cpp:10
-          finished = true;
-        else
-        {
-          nHits++;
-          pixelOf(a.g, i, w, h);
-          rnd = rtd::rand01(w, h, a.sampBegin + s);
-          if (regen) // the primary ray was never stored: same function, same bits (only paths that hit need it)
-            rtd::primaryRay(*a.cam, a.g.width, a.g.height, w, h, a.sampBegin + s, rnd, o, d);
-          const float pr = rt::maxRef(rt::maxRef(albedo.x, albedo.y), albedo.z); // :13
-          if (a.depth > 5)                                                      // :19 (depth >= maxDepth never reaches here)
-          {
-            if (rnd.z >= pr)
-              finished = true;
-            else
-              material = material / pr;
-          }
-        }
-      }
-      if (finished)
-      {
-        if (a.depth == 0)
-          a.pb.live[p] = kDeadZero; // a primary miss adds exactly +0 to the accumulator: nothing to store
-        else
-        {
-          a.pb.s0[p] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-          a.pb.live[p] = kDead;
-        }
-      }
-      else
-      {
-        const float4* tp = reinterpret_cast<const float4*>(a.scene.tris + rec);
-        const float4 a2 = tp[2], a3 = tp[3];
-        const vec3 n{a2.y, a2.z, a2.w};
-        if (a.depth < a.aovDepths)
-          a.aovTri[((size_t)s * a.aovDepths + a.depth) * a.g.numLocalPixels + i] = __float_as_uint(a3.x);
-        const float payloadEmissive = a.depth == 0 ? 1.0f : 0.0f;                  // Ray.h:10, CPUScene.cpp:61
-        radiance = radiance + material * emissive * payloadEmissive;              // :27
-        material = material * albedo;                                             // :28
-        const vec3 position = o + d * t;                                          // :238
-        a.pb.rayO[p] = make_float4(position.x, position.y, position.z, n.x);
-        a.pb.s0[p] = make_float4(radiance.x, radiance.y, radiance.z, n.y);
-        a.pb.nz[p] = n.z;
-        if (a.depth + 1 < a.maxDepth) // the last shaded depth traces no bounce ray: neither direction nor throughput is kept
-        {
-          const vec3 normalLight = rt::dot(n, d) < 0 ? n : -n;                    // :240
-          const vec3 nd = rtd::bounceDirection(normalLight, rnd);                 // :54-60
-          a.pb.rayD[p] = make_float4(nd.x, nd.y, nd.z, material.x);
-          a.pb.s1[p] = make_float2(material.y, material.z);
-        }
-        a.pb.live[p] = (uint8_t)(a.depth + 1);
-        nAlive++;
-        survives = true;
-      }
-    }
-    if (SPARSE)
-    {
-      // append the survivors to the next depth's slot list: one atomic per wave, ranks from the ballot
-      const uint64_t m = __ballot(survives);
-      if (m)
-      {
-        uint32_t base = 0;
-        if (laneId() == (uint32_t)__ffsll((long long)m) - 1)
-          base = atomicAdd(&a.counters->listCount[a.depth + 1], (uint32_t)__popcll(m));
-        base = __shfl(base, __ffsll((long long)m) - 1);
-        if (survives)
-          a.listNext[base + rankIn(m)] = p;
-      }
-    }
-  }
-  // block tallies: one atomic per block and counter
-  for (int off = 32; off > 0; off >>= 1)
-  {
-    nAlive += __shfl_down(nAlive, off);
-    nHits += __shfl_down(nHits, off);
-  }
-  const uint32_t wv = threadIdx.x >> 6;
-  if ((threadIdx.x & 63u) == 0)
-  {
-    sAlive[wv] = nAlive;
-    sHits[wv] = nHits;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0)
-  {
-    uint32_t ta = 0, th = 0;
-    for (uint32_t k = 0; k < kWavesPerBlock; ++k)
-    {
-      ta += sAlive[k];
-      th += sHits[k];
-    }
-    if (ta)
-      atomicAdd(&a.counters->alive[a.depth + 1], (unsigned long long)ta);
-    if (th)
-      atomicAdd(&a.counters->hits[a.depth < 15 ? a.depth : 15], (unsigned long long)th);
-  }
-}
-
-// dense -> sparse hand-over: collects the slots alive at `depth` into a list (order: ascending slot within a
-// block's 4096-slot span, spans in arrival order).  One atomic per block.
-__global__ __launch_bounds__(kBlock) void k_compact(PathBuffers pb, uint32_t numSlots, uint32_t depth, uint32_t* list, uint32_t capacity,
-                                                    DeviceCounters* counters)
-{
-  __shared__ uint32_t sWave[kWavesPerBlock];
-  __shared__ uint32_t sBase;
-  const uint32_t lane = laneId(), wv = threadIdx.x >> 6;
-  const uint32_t spanBase = blockIdx.x * (kBlock * 16) + threadIdx.x * 16;
-  uint32_t bits = 0, cnt = 0;
-  if (spanBase < numSlots) // numSlots is a multiple of 64, the buffer is padded: the 16-byte load stays in bounds
-  {
-    const uint4 v = *reinterpret_cast<const uint4*>(pb.live + spanBase);
-    const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if (spanBase + k < numSlots && ((wds[k >> 2] >> ((k & 3) * 8)) & 0xffu) == depth)
-      {
-        bits |= 1u << k;
-        cnt++;
-      }
-  }
-  // exclusive prefix of cnt over the wave, then over the block
-  uint32_t incl = cnt;
-  for (int off = 1; off < 64; off <<= 1)
-  {
-    const uint32_t up = __shfl_up(incl, off);
-    if ((int)lane >= off)
-      incl += up;
-  }
-  if (lane == 63)
-    sWave[wv] = incl;
-  __syncthreads();
-  if (threadIdx.x == 0)
-  {
-    uint32_t tot = 0;
-    for (uint32_t k = 0; k < kWavesPerBlock; ++k)
-    {
-      const uint32_t c = sWave[k];
-      sWave[k] = tot;
-      tot += c;
-    }
-    sBase = tot ? atomicAdd(&counters->listCount[depth], tot) : 0u;
-  }
-  __syncthreads();
-  uint32_t dst = sBase + sWave[wv] + (incl - cnt);
-  for (int k = 0; k < 16; ++k)
-    if ((bits >> k) & 1u)
-    {
-      if (dst < capacity)
-        list[dst] = spanBase + k;
-      dst++;
-    }
-}
-
-// accumulator[pix] += radiance / float(N), sample passes in ascending order (CPURenderer.cpp:197)
-// `fresh` = first batch of a frame: the accumulator is taken as zero instead of being loaded (saves clearing it beforehand)
-__global__ __launch_bounds__(kBlock) void k_accumulate(FrameGeom g, PathBuffers pb, float* acc, uint32_t numBatchSamples, uint32_t fresh)
-{
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= g.numLocalPixels)
-    return;
-  float r = 0, gg = 0, b = 0;
-  bool loaded = fresh != 0; // 0 + x == x and 0 + 0 == +0: starting from zero is what the cleared accumulator would give
-  const float n = float(g.numSamples);
-  for (uint32_t s = 0; s < numBatchSamples; ++s)
-  {
-    const size_t p = (size_t)s * g.numLocalPixels + i;
-    // kDeadZero: the sample's radiance is exactly +0 (primary miss) -> adding 0/N leaves the sum unchanged
-    if (pb.live[p] != kDead)
-      continue;
-    if (!loaded)
-    {
-      r = acc[3 * (size_t)i], gg = acc[3 * (size_t)i + 1], b = acc[3 * (size_t)i + 2];
-      loaded = true;
-    }
-    const float4 v = pb.s0[p];
-    r += v.x / n;
-    gg += v.y / n;
-    b += v.z / n;
-  }
-  if (loaded)
-  {
-    acc[3 * (size_t)i] = r;
-    acc[3 * (size_t)i + 1] = gg;
-    acc[3 * (size_t)i + 2] = b;
-  }
-}
-
-// image = pow(max(accumulator * resolver, 0), 0.45)  (CPURenderer.cpp:196,198); display only
-__global__ __launch_bounds__(kBlock) void k_tonemap(const float* acc, float* img, uint32_t numFloats, float resolver)
-{
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i < numFloats)
-    img[i] = powf(rt::maxRef(acc[i] * resolver, 0.0f), 0.45f);
-}
-
-// tile-major -> row-major scatter (multi-GPU assembly and read-back)
-__global__ __launch_bounds__(kBlock) void k_untile(FrameGeom g, const float* tileMajor, float* rowMajor, uint32_t numPixels)
-{
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= numPixels)
-    return;
-  uint32_t w, h;
-  if (!pixelOf(g, i, w, h))
-    return;
-  const size_t dst = 3 * ((size_t)h * g.width + w);
-  rowMajor[dst] = tileMajor[3 * (size_t)i];
-  rowMajor[dst + 1] = tileMajor[3 * (size_t)i + 1];
-  rowMajor[dst + 2] = tileMajor[3 * (size_t)i + 2];
-}
-
-// ------------------------------------------------------------------------------------------------ probes
-// adds one batch's tallies to the frame totals (device memory), so a frame needs no host round trip between batches
-__global__ void k_fold_counters(const DeviceCounters* batch, rthip_counters* totals)
-{
-  if (threadIdx.x != 0 || blockIdx.x != 0)
-    return;
-  // atomics: two batches in flight on two streams may fold at the same time
-  auto add = [](uint64_t* dst, unsigned long long v) {
-    if (v)
-      atomicAdd(reinterpret_cast<unsigned long long*>(dst), v);
-  };
-  add(&totals->extendPrimary, batch->extendPrimary);
-  add(&totals->extendSecondary, batch->extendSecondary);
-  add(&totals->shadow, batch->shadow);
-  add(&totals->nodesVisited, batch->nodesVisited);
-  add(&totals->trisTested, batch->trisTested);
-  add(&totals->nonFiniteAccepts, batch->nonFinite);
-  add(&totals->nodesVisitedExtend, batch->nodesExtend);
-  add(&totals->trisTestedExtend, batch->trisExtend);
-  add(&totals->waveNodeSteps, batch->waveNodeSteps);
-  add(&totals->waveLeafSteps, batch->waveLeafSteps);
-  for (int i = 0; i < 16; ++i)
-    add(&totals->hits[i], batch->hits[i]);
-}
-
-__global__ void k_probe_rand01(const uint32_t* xyz, uint32_t n, float* out)
-{
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n)
-    return;
-  const vec3 r = rtd::rand01(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
-  out[3 * i] = r.x, out[3 * i + 1] = r.y, out[3 * i + 2] = r.z;
-}
-__global__ void k_probe_sincos(const float* x, uint32_t n, float* s, float* c)
-{
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n)
-    rtd::sincosDet(x[i], s[i], c[i]);
-}
-__global__ void k_probe_rays(const CameraConsts* camp, uint32_t width, uint32_t height, const uint32_t* whs, uint32_t n, float* o3, float* d3)
-{
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n)
-    return;
-  const CameraConsts k = *camp;
-  const uint32_t w = whs[3 * i], h = whs[3 * i + 1], s = whs[3 * i + 2];
-  vec3 o, d;
-  rtd::primaryRay(k, width, height, w, h, s, rtd::rand01(w, h, s), o, d);
-  o3[3 * i] = o.x, o3[3 * i + 1] = o.y, o3[3 * i + 2] = o.z;
-  d3[3 * i] = d.x, d3[3 * i + 1] = d.y, d3[3 * i + 2] = d.z;
-}
-__global__ void k_probe_bounce(const float* n3, const float* r3, uint32_t n, float* d3)
-{
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n)
-    return;
-  const vec3 d = rtd::bounceDirection(vec3{n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]}, vec3{r3[3 * i], r3[3 * i + 1], r3[3 * i + 2]});
-  d3[3 * i] = d.x, d3[3 * i + 1] = d.y, d3[3 * i + 2] = d.z;
-}
-__global__ void k_probe_pack(const float* o3, const float* d3, uint32_t n, float4* ro, float4* rd, uint8_t* live)
-{
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n)
-    return;
-  ro[i] = make_float4(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2], 0.0f);
-  rd[i] = make_float4(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2], 0.0f);
-  live[i] = 0;
-}
-__global__ void k_probe_unpack(const DeviceScene scene, const uint2* hit, uint32_t n, uint32_t* triId, float* t)
-{
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n)
-    return;
-  const uint2 h = hit[i];
-  t[i] = __uint_as_float(h.x);
-  triId[i] = (h.y == RTFLAT_INVALID) ? RTFLAT_INVALID : scene.tris[h.y].triId;
-}
-
 template <typename T>
 struct DevBuf
 {

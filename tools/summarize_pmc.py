@@ -18,7 +18,7 @@ MODES = {0: "CLOSEST", 1: "SHADOW", 2: "ANYPROBE", 3: "PRIMARY", 4: "PRIMARY_GRO
 
 
 def short_name(full):
-    s = full.replace("(anonymous namespace)::", "")
+    s = full.replace("(anonymous namespace)::", "").replace("rtk::", "")
     s = re.sub(r"^void\s+", "", s)
     m = re.match(r"k_trace<(\d+),\s*(true|false)>", s)
     if m:
