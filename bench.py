@@ -50,8 +50,10 @@ def workloads():
                       name="stanford-bunny.obj (69,451 tris) 1920x1080 16spp primary+shadow"),
         "soup1m": dict(spec=lambda: scenes.soup_scene(1 << 20, 0x5EED0001, 0.02), width=1920, height=1080, spp=1, max_depth=4, flat_cpu=True,
                        name="triangle soup 2^20 tris seed 0x5EED0001, 1920x1080 1spp primary+3 bounces [BASELINE configs[2]]"),
-        "hf10m": dict(spec=lambda: scenes.heightfield_scene(2236, 0x5EED0002), width=3840, height=2160, spp=4, max_depth=12, flat_cpu=True,
-                      name="height field 2236^2 quads = 9,999,392 tris seed 0x5EED0002, 3840x2160 4spp [BASELINE configs[3] scene]"),
+        "hf10m": dict(spec=lambda: scenes.heightfield_scene(2236, 0x5EED0002), width=3840, height=2160, spp=64, max_depth=12, flat_cpu=True,
+                      name="height field 2236^2 quads = 9,999,392 tris seed 0x5EED0002, 3840x2160 64spp full paths [BASELINE configs[3]]"),
+        "hf10m4": dict(spec=lambda: scenes.heightfield_scene(2236, 0x5EED0002), width=3840, height=2160, spp=4, max_depth=12, flat_cpu=True,
+                       name="height field 2236^2 quads = 9,999,392 tris seed 0x5EED0002, 3840x2160 4spp full paths (quick variant of configs[3])"),
     }
 
 

@@ -16,7 +16,7 @@ done
 timeout -k 10 300 python3 bench.py > profiles/${TAG}_cube_bench.json 2> gpurun_out/${TAG}_cube_bench.err || { echo "bench cube failed"; tail -5 gpurun_out/${TAG}_cube_bench.err; exit 1; }
 timeout -k 10 300 python3 bench.py --workload soup1m > profiles/${TAG}_soup1m_bench.json 2> gpurun_out/${TAG}_soup1m_bench.err || { echo "bench soup failed"; exit 1; }
 timeout -k 10 300 python3 bench.py --workload bunny > profiles/${TAG}_bunny_bench.json 2> gpurun_out/${TAG}_bunny_bench.err || { echo "bench bunny failed"; exit 1; }
-timeout -k 10 400 python3 bench.py --workload hf10m --steps 5 --warmup 1 > profiles/${TAG}_hf10m_bench.json 2> gpurun_out/${TAG}_hf10m_bench.err || { echo "bench hf10m failed"; exit 1; }
+timeout -k 10 400 python3 bench.py --workload hf10m --steps 3 --warmup 1 > profiles/${TAG}_hf10m_bench.json 2> gpurun_out/${TAG}_hf10m_bench.err || { echo "bench hf10m failed"; exit 1; }
 cp profiles/*.json profiles/*.csv gpurun_out/ 2>/dev/null
 mkdir -p gpurun_out/profiles_${TAG} && cp profiles/${TAG}_* profiles/traffic.json gpurun_out/profiles_${TAG}/
 cat profiles/${TAG}_cube_bench.json
