@@ -40,7 +40,7 @@ def weak_resolution(base_w, base_h, n):
 
 
 def workloads():
-    from tests import scenes
+    from raytracer_amd import scenes
     return {
         "cube": dict(spec=scenes.cube_scene, width=1920, height=1080, spp=16, max_depth=1, flat_cpu=False,
                      name="cube (== res/models/cube.fbx, main.cpp scene) 1920x1080 16spp primary+shadow [BASELINE configs[1]]"),
@@ -312,7 +312,8 @@ def main():
     # ---- CPU baseline: the oracle (restated src/cpu ThreadPool path) on this box's host cores, bounded sample
     cpu = None
     if not args.no_cpu_baseline:
-        from oracle import binding as ob  # the checker / baseline, never the thing measured above
+        from tests import scenes as oracle_side  # the checker / baseline (imports oracle/), never the thing measured above
+        spec.__class__ = oracle_side.SceneSpec
         oracle = spec.build_oracle()
         bw, bh = wl["width"], wl["height"]
         if wl["flat_cpu"]:

@@ -5,4 +5,5 @@ raytracer_amd/src (host C++ mirroring the reference's src/scene, src/util and a 
 of include/raytracer_c.h).  This Python package is only the ctypes binding used by tests, bench.py and the
 multi-GPU launcher.
 """
+from . import capi, scenes  # noqa: F401
 from .capi import Camera, Mesh, Probe, Renderer, RtError, make_camera  # noqa: F401

@@ -56,6 +56,21 @@ struct DevBuf
 {
   T* p = nullptr;
   size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr, o.n = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept
+  {
+    if (this != &o)
+    {
+      release();
+      p = o.p, n = o.n;
+      o.p = nullptr, o.n = 0;
+    }
+    return *this;
+  }
+  ~DevBuf() { release(); } // every early return of a probe / untile call frees what it had allocated
   int ensure(size_t count)
   {
     if (count <= n && p)
@@ -539,17 +554,8 @@ const char* rthip_error_string(int code)
   }
 }
 
-int rthip_create(int device, rthip_ctx** out)
+static int createContext(rthip_ctx* c, int device)
 {
-  if (!out)
-    return RTHIP_E_ARG;
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
-    return RTHIP_E_NODEVICE;
-  HIPCHK(hipSetDevice(device));
-  rthip_ctx* c = new (std::nothrow) rthip_ctx();
-  if (!c)
-    return RTHIP_E_ARG;
   c->device = device;
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -585,6 +591,25 @@ int rthip_create(int device, rthip_ctx** out)
   HIPCHK(hipEventCreateWithFlags(&c->alt.evFork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->alt.evJoin, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->alt.evDone, hipEventDisableTiming));
+  return 0;
+}
+
+int rthip_create(int device, rthip_ctx** out)
+{
+  if (!out)
+    return RTHIP_E_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+    return RTHIP_E_NODEVICE;
+  HIPCHK(hipSetDevice(device));
+  rthip_ctx* c = new (std::nothrow) rthip_ctx();
+  if (!c)
+    return RTHIP_E_ARG;
+  if (int rc = createContext(c, device))
+  {
+    rthip_destroy(c); // streams / events created so far (null handles are skipped)
+    return rc;
+  }
   *out = c;
   return 0;
 }
@@ -594,24 +619,30 @@ int rthip_destroy(rthip_ctx* c)
   if (!c)
     return RTHIP_E_ARG;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->alt.stream);
-  (void)hipStreamSynchronize(c->stream);
-  c->modelNodes.release(), c->nodes.release(), c->tris.release(), c->lights.release(), c->tileIds.release(), c->camConsts.release();
-  c->rayO.release(), c->rayD.release(), c->s0.release(), c->s1.release(), c->nz.release(), c->hit.release(), c->live.release(), c->mask.release();
-  c->anyOut.release(), c->acc.release(), c->img.release(), c->rowScratch.release(), c->aovTri.release(), c->aovShadow.release();
-  c->spill.release(), c->spill2.release(), c->fetch.release(), c->listA.release(), c->listB.release(), c->totals.release();
-  (void)hipEventDestroy(c->evA), (void)hipEventDestroy(c->evB), (void)hipEventDestroy(c->evK0), (void)hipEventDestroy(c->evK1);
+  auto dropStream = [](hipStream_t& s) {
+    if (s)
+    {
+      (void)hipStreamSynchronize(s);
+      (void)hipStreamDestroy(s);
+    }
+    s = nullptr;
+  };
+  auto dropEvent = [](hipEvent_t& e) {
+    if (e)
+      (void)hipEventDestroy(e);
+    e = nullptr;
+  };
+  if (c->alt.stream)
+    (void)hipStreamSynchronize(c->alt.stream);
+  if (c->stream)
+    (void)hipStreamSynchronize(c->stream);
+  dropStream(c->alt.stream2), dropStream(c->alt.stream), dropStream(c->stream2), dropStream(c->stream);
+  dropEvent(c->evA), dropEvent(c->evB), dropEvent(c->evK0), dropEvent(c->evK1);
   for (hipEvent_t e : c->timerEvents)
     (void)hipEventDestroy(e);
-  (void)hipEventDestroy(c->evFork), (void)hipEventDestroy(c->evJoin), (void)hipEventDestroy(c->evDone), (void)hipEventDestroy(c->evFrame);
-  (void)hipEventDestroy(c->alt.evFork), (void)hipEventDestroy(c->alt.evJoin), (void)hipEventDestroy(c->alt.evDone);
-  (void)hipStreamDestroy(c->alt.stream), (void)hipStreamDestroy(c->alt.stream2);
-  c->alt.rayO.release(), c->alt.rayD.release(), c->alt.s0.release(), c->alt.s1.release(), c->alt.nz.release(), c->alt.hit.release();
-  c->alt.live.release(), c->alt.mask.release(), c->alt.spill.release(), c->alt.spill2.release(), c->alt.fetch.release();
-  c->alt.listA.release(), c->alt.listB.release();
-  (void)hipStreamDestroy(c->stream2);
-  (void)hipStreamDestroy(c->stream);
-  delete c;
+  dropEvent(c->evFork), dropEvent(c->evJoin), dropEvent(c->evDone), dropEvent(c->evFrame);
+  dropEvent(c->alt.evFork), dropEvent(c->alt.evJoin), dropEvent(c->alt.evDone);
+  delete c; // the DevBuf members free their device memory
   return 0;
 }
 

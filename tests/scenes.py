@@ -1,47 +1,17 @@
 """Scene recipes shared by the tests: every recipe feeds the SAME arrays, lights and camera to the product renderer
-(raytracer_amd, through its C ABI) and to the CPU oracle (oracle/, test infrastructure)."""
-import os
+(raytracer_amd.scenes, through the C ABI) and to the CPU oracle (oracle/, test infrastructure).  The recipes themselves live
+in the package; this module only adds the oracle's side to each spec."""
+import functools
 
-import numpy as np
-
-import raytracer_amd as ra
+import raytracer_amd as ra  # noqa: F401  (tests reach ra.* through this module's importers)
 from oracle import binding as ob
-
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-
-
-def main_light_dir():
-    """glm::normalize(vec3(-0.4,-0.3,-0.2)) of the reference's main.cpp:10, in fp32 with glm's operation order."""
-    d = np.array([-0.4, -0.3, -0.2], np.float32)
-    s = np.float32(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
-    return d * (np.float32(1.0) / np.sqrt(s))
+from raytracer_amd import scenes as _ps
+from raytracer_amd.scenes import GOLDEN, MAIN_CAMERA, main_light_dir, scale, translate  # noqa: F401
 
 
-def translate(x, y, z):
-    m = np.eye(4, dtype=np.float32)
-    m[:3, 3] = (x, y, z)
-    return m
-
-
-def scale(s):
-    m = np.eye(4, dtype=np.float32)
-    m[0, 0] = m[1, 1] = m[2, 2] = s
-    return m
-
-
-class SceneSpec:
-    def __init__(self, name, meshes, camera, dir_lights=None, point_lights=None):
-        self.name = name
-        self.meshes = meshes  # list of (ra.Mesh, 4x4 transform)
-        self.camera = camera  # dict(position, target, S_O, f, A)
-        self.dir_lights = [(main_light_dir(), (1, 1, 1))] if dir_lights is None else dir_lights
-        self.point_lights = [((0, 0, 0), (1, 1, 1), 1.0)] if point_lights is None else point_lights
-
+class SceneSpec(_ps.SceneSpec):
     def oracle_camera(self):
         return ob.make_camera(**self.camera)
-
-    def product_camera(self):
-        return ra.make_camera(**self.camera)
 
     def build_oracle(self, fix_edge_offset=False):
         s = ob.OracleScene(fix_edge_offset=fix_edge_offset)
@@ -55,74 +25,24 @@ class SceneSpec:
         s.generate()
         return s
 
-    def build_product(self, backend="hip", options=None, device=0):
-        r = ra.Renderer(backend, device)
-        for d, c in self.dir_lights:
-            r.add_directional_light(d, c)
-        for p, c, a in self.point_lights:
-            r.add_point_light(p, c, a)
-        for mesh, t in self.meshes:
-            r.add_mesh(mesh, t)
-        for k, v in (options or {}).items():
-            r.set_option(k, v)
-        r.generate()
-        return r
+
+def _with_oracle(recipe):
+    @functools.wraps(recipe)
+    def make(*args, **kwargs):
+        spec = recipe(*args, **kwargs)
+        spec.__class__ = SceneSpec
+        return spec
+    return make
 
 
-MAIN_CAMERA = dict(position=(5, 1, 2), target=(0, 0, 0), S_O=6, f=0, A=0)  # main.cpp:18-24
-
-
-def cube_scene():
-    """The reference's own scene (main.cpp:9-24) with the procedural stand-in for cube.fbx."""
-    return SceneSpec("cube", [(ra.Mesh.cube(), ra.capi.IDENTITY)], MAIN_CAMERA)
-
-
-def bunny_mesh():
-    z = np.load(os.path.join(GOLDEN, "bunny_mesh.npz"))
-    return ra.Mesh.from_arrays(z["positions"], z["indices"])
-
-
-def bunny_scene():
-    return SceneSpec("bunny", [(bunny_mesh(), ra.capi.IDENTITY)],
-                     dict(position=(0.05, 0.18, 0.35), target=(-0.02, 0.1, 0.0), S_O=6, f=0, A=0),
-                     point_lights=[((0.0, 0.1, 0.1), (1, 1, 1), 1.0)])
-
-
-def soup_scene(num_tris=20000, seed=0x5EED0001, radius=0.05, lens=False):
-    cam = dict(position=(0, 0, 4), target=(0, 0, 0), S_O=4, f=0.05 if lens else 0, A=0.02 if lens else 0)
-    return SceneSpec(f"soup{num_tris}", [(ra.Mesh.soup(num_tris, seed, radius), ra.capi.IDENTITY)], cam)
-
-
-def heightfield_scene(quads=96, seed=0x5EED0002):
-    return SceneSpec(f"hf{quads}", [(ra.Mesh.heightfield(quads, seed, 0.15), ra.capi.IDENTITY)],
-                     dict(position=(0.3, 1.2, 2.2), target=(0, 0, 0), S_O=6, f=0, A=0),
-                     dir_lights=[(main_light_dir(), (1, 1, 1)), (np.array([0.6, -0.64, 0.48], np.float32), (0.5, 0.25, 0.125))])
-
-
-def multi_model_scene():
-    """Three models: exercises the model-level tree, the DFS tie order and the reference's edge-pool indexing."""
-    meshes = [(ra.Mesh.cube(), translate(-1.6, 0, 0) @ scale(0.7)),
-              (ra.Mesh.soup(300, 7, 0.4), ra.capi.IDENTITY),
-              (ra.Mesh.cube(), translate(1.4, 0.3, -0.2) @ scale(0.5)),
-              (ra.Mesh.heightfield(8, 3, 0.3), translate(0, -1.2, 0))]
-    return SceneSpec("multi", meshes, dict(position=(1.0, 2.0, 6.0), target=(0, 0, 0), S_O=6, f=0, A=0))
-
-
-def glb_meshes(name):
-    """Meshes of the reference's res/models/<name>.glb (fixture: tests/golden/glb_meshes.npz, one per mesh primitive)."""
-    z = np.load(os.path.join(GOLDEN, "glb_meshes.npz"))
-    return [ra.Mesh.from_arrays(z["%s_%d_positions" % (name, k)], z["%s_%d_indices" % (name, k)]) for k in range(int(z[name + "_count"]))]
-
-
-def box_glb_scene():
-    """res/models/box.glb as ModelLoader::loadModel + addModel(identity) would set it up: a cube inside five wall quads at
-    +-10, every mesh a model of its own.  Two walls are exactly flat (invisible to the reference's strict slab test), three
-    are 2e-6 thick."""
-    return SceneSpec("box_glb", [(m, ra.capi.IDENTITY) for m in glb_meshes("box")], MAIN_CAMERA)
-
-
-def town_hall_scene():
-    """res/models/town_hall.glb (two meshes, 58 triangles)."""
-    return SceneSpec("town_hall", [(m, ra.capi.IDENTITY) for m in glb_meshes("town_hall")],
-                     dict(position=(16.0, 7.0, 15.0), target=(2.5, 2.0, 0.0), S_O=6, f=0, A=0),
-                     point_lights=[((2.0, 2.0, 0.0), (1.0, 0.8, 0.6), 12.0)])
+cube_scene = _with_oracle(_ps.cube_scene)
+bunny_scene = _with_oracle(_ps.bunny_scene)
+soup_scene = _with_oracle(_ps.soup_scene)
+heightfield_scene = _with_oracle(_ps.heightfield_scene)
+multi_model_scene = _with_oracle(_ps.multi_model_scene)
+box_glb_scene = _with_oracle(_ps.box_glb_scene)
+town_hall_scene = _with_oracle(_ps.town_hall_scene)
+soup1m_scene = _with_oracle(_ps.soup1m_scene)
+hf10m_scene = _with_oracle(_ps.hf10m_scene)
+bunny_mesh = _ps.bunny_mesh
+glb_meshes = _ps.glb_meshes
