@@ -143,6 +143,18 @@ int rthip_probe_bounce(rthip_ctx* ctx, const float* normalLight3, const float* r
 int rthip_probe_trace(rthip_ctx* ctx, const float* origin3, const float* dir3, uint32_t n, float tmin, float tmax,
                       uint32_t* triIdOut, float* tOut, uint8_t* anyOut);
 
+/* Allocation-free variant of rthip_probe_trace.  It has NO counterpart in the reference; it exists for callers that cannot
+ * allocate: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels and results
+ * as rthip_probe_trace, but every pointer is DEVICE memory on the context's GPU (origins / directions: 3 floats per ray;
+ * outputs: n entries each) and all working memory (ray and hit records, liveness bytes, work counters, traversal-stack
+ * spill) lives in a static device array of about 6.3 MiB that each GPU the library runs on holds until the process ends.
+ * The call performs no hipMalloc / hipFree (nor any other allocating routine) and returns once the outputs are written.
+ * Limits: n <= RTHIP_STATIC_MAX_RAYS, otherwise RTHIP_E_LIMIT ("size beyond a compiled-in limit").  Every call on a GPU
+ * shares that GPU's array: calls that overlap on one GPU (two contexts, two threads) race; serialise them. */
+#define RTHIP_STATIC_MAX_RAYS 16384u
+int rthip_trace_rays_static(rthip_ctx* ctx, const float* originDev3, const float* dirDev3, uint32_t n, float tmin, float tmax,
+                            uint32_t* triIdDev, float* tDev, uint8_t* anyDev);
+
 const char* rthip_error_string(int code);
 
 #ifdef __cplusplus

@@ -14,6 +14,7 @@ LIB_HOST = os.path.join(_HERE, "libraytracer_amd.so")
 LIB_HIP = os.path.join(_HERE, "librthip.so")
 
 RTHIP_E_ARG, RTHIP_E_STATE, RTHIP_E_BOUNDS, RTHIP_E_NODEVICE, RTHIP_E_LIMIT = -1, -2, -3, -4, -5
+RTHIP_STATIC_MAX_RAYS = 16384  # include/rthip.h
 
 
 class RtError(RuntimeError):
@@ -84,6 +85,7 @@ def hip_lib():
         L.rthip_probe_primary_rays.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, up, C.c_uint32, fp, fp]
         L.rthip_probe_bounce.argtypes = [vp, fp, fp, C.c_uint32, fp]
         L.rthip_probe_trace.argtypes = [vp, fp, fp, C.c_uint32, C.c_float, C.c_float, up, fp, C.POINTER(C.c_uint8)]
+        L.rthip_trace_rays_static.argtypes = [vp, vp, vp, C.c_uint32, C.c_float, C.c_float, vp, vp, vp]
         L.rthip_accumulator_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
         L.rthip_untile.argtypes = [vp, vp, up, C.c_uint32, vp]
         L.rthip_copy_accumulator_to.argtypes = [vp, vp, C.c_uint64]

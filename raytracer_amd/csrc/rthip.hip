@@ -91,7 +91,51 @@ struct DevBuf
     n = 0;
   }
 };
+
+// Lends memory the context does not own (the static scratch array of rthip_trace_rays_static) to one of its buffers for
+// the duration of a call; the buffer's own pointer comes back when the guard goes out of scope, so nothing borrowed is
+// ever freed.
+template <typename T>
+struct Borrow
+{
+  DevBuf<T>& b;
+  T* p;
+  size_t n;
+  Borrow(DevBuf<T>& buf, void* mem, size_t count) : b(buf), p(buf.p), n(buf.n) { b.p = static_cast<T*>(mem), b.n = count; }
+  ~Borrow() { b.p = p, b.n = n; }
+  Borrow(const Borrow&) = delete;
+  Borrow& operator=(const Borrow&) = delete;
+};
 } // namespace
+
+// ---- static scratch of the allocation-free entry point (rthip_trace_rays_static) -------------------------------------
+// One array per GPU the library runs on, held until the process ends.  Layout (all offsets multiples of 256 B):
+//   [rayO | rayD | hit | live | batch counters + work-fetch counters | stack spill]
+// Host code never uses the array's name as an address: rthip_create resolves it once per device with
+// hipGetSymbolAddress (that device current) and every launch / memset takes the resolved pointer.
+namespace
+{
+constexpr uint32_t kStaticMaxRays = RTHIP_STATIC_MAX_RAYS;
+constexpr uint32_t kStaticSpillCap = rtk::kMaxStack - rtk::kStackLds; // deepest spill any accepted BVH can need
+constexpr size_t kStaticCounterWords = ((sizeof(rtk::DeviceCounters) + 255) / 256) * 64;
+constexpr size_t kStaticFetchWords = kStaticCounterWords + 2 * (size_t)rtk::kFetchShards * rtk::kFetchStride; // two traversal launches
+constexpr size_t kStaticOffRayO = 0;
+constexpr size_t kStaticOffRayD = kStaticOffRayO + (size_t)kStaticMaxRays * sizeof(float4);
+constexpr size_t kStaticOffHit = kStaticOffRayD + (size_t)kStaticMaxRays * sizeof(float4);
+constexpr size_t kStaticOffLive = kStaticOffHit + (size_t)kStaticMaxRays * sizeof(uint2);
+constexpr size_t kStaticOffFetch = kStaticOffLive + (((size_t)kStaticMaxRays + 64 + 255) / 256) * 256;
+constexpr size_t kStaticOffSpill = kStaticOffFetch + ((kStaticFetchWords * 4 + 255) / 256) * 256;
+// a launch over <= kStaticMaxRays items uses 64-item chunks, i.e. at most kStaticMaxRays/64 waves = kStaticMaxRays lanes
+constexpr size_t kStaticSpillWords = (size_t)kStaticSpillCap * kStaticMaxRays;
+constexpr size_t kStaticBytes = kStaticOffSpill + kStaticSpillWords * 4;
+static_assert(kStaticBytes <= (8u << 20), "the static scratch is meant to stay modest (8 MiB)");
+constexpr int kMaxDevices = 64;
+} // namespace
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+namespace
+{
+unsigned char* g_scratchPtr[kMaxDevices] = {}; // device address of `scratch` on each GPU (each GPU holds its own copy)
+}
 
 struct rthip_ctx
 {
@@ -576,6 +620,13 @@ static int createContext(rthip_ctx* c, int device)
       c->pipelineBatches = std::min(pl, 16u);
   }
   c->traceBlocks = (uint32_t)c->numCUs * c->tuneBlocks; // 6 blocks x 4 waves = 24 waves per CU: what 24 KB of LDS per block admits
+  // the static scratch of rthip_trace_rays_static: resolved once per device, with that device current
+  if (device < kMaxDevices && !g_scratchPtr[device])
+  {
+    void* sp = nullptr;
+    HIPCHK(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
+    g_scratchPtr[device] = static_cast<unsigned char*>(sp);
+  }
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&c->evA));
   HIPCHK(hipEventCreate(&c->evB));
@@ -1215,6 +1266,51 @@ int rthip_probe_trace(rthip_ctx* c, const float* origin3, const float* dir3, uin
   HIPCHK(hipMemcpy(tOut, t.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(anyOut, c->anyOut.p, (size_t)n, hipMemcpyDeviceToHost));
   o.release(), d.release(), t.release(), id.release();
+  return 0;
+}
+
+// The allocation-free variant of rthip_probe_trace (no counterpart in the reference; for callers that cannot allocate).
+// Same kernels, same launches; every buffer beyond the caller's inputs and outputs lives in this GPU's static `scratch`.
+int rthip_trace_rays_static(rthip_ctx* c, const float* originDev3, const float* dirDev3, uint32_t n, float tmin, float tmax,
+                            uint32_t* triIdDev, float* tDev, uint8_t* anyDev)
+{
+  if (!c || !originDev3 || !dirDev3 || !n || !triIdDev || !tDev || !anyDev)
+    return RTHIP_E_ARG;
+  if (!c->haveScene)
+    return RTHIP_E_STATE;
+  if (n > kStaticMaxRays)
+    return RTHIP_E_LIMIT; // "rthip: size beyond a compiled-in limit": at most RTHIP_STATIC_MAX_RAYS rays per call
+  if (c->spillCap > kStaticSpillCap || c->device >= kMaxDevices || !g_scratchPtr[c->device])
+    return RTHIP_E_LIMIT;
+  HIPCHK(hipSetDevice(c->device));
+  unsigned char* base = g_scratchPtr[c->device]; // the resolved device address, never the symbol's name
+  // the context's own buffers step aside for the duration of the call (restored on every return path)
+  Borrow<float4> bRayO(c->rayO, base + kStaticOffRayO, kStaticMaxRays), bRayD(c->rayD, base + kStaticOffRayD, kStaticMaxRays);
+  Borrow<uint2> bHit(c->hit, base + kStaticOffHit, kStaticMaxRays);
+  Borrow<uint8_t> bLive(c->live, base + kStaticOffLive, kStaticMaxRays + 64), bAny(c->anyOut, anyDev, n);
+  Borrow<uint32_t> bFetch(c->fetch, base + kStaticOffFetch, kStaticFetchWords), bSpill(c->spill, base + kStaticOffSpill, kStaticSpillWords);
+  const uint32_t keepCursor = c->fetchCursor;
+  const bool keepTiming = c->kernelTiming;
+  c->kernelTiming = false; // the kernel timer creates events on demand: not in a call that must not allocate
+  struct Restore
+  {
+    rthip_ctx* c;
+    uint32_t cursor;
+    bool timing;
+    ~Restore() { c->fetchCursor = cursor, c->kernelTiming = timing; }
+  } restore{c, keepCursor, keepTiming};
+  // the array keeps the previous call's contents: counters and work-fetch cursors must start at zero; ray records, hit
+  // records and liveness bytes of the n slots in use are all rewritten below before anything reads them
+  HIPCHK(hipMemsetAsync(c->fetch.p, 0, kStaticFetchWords * sizeof(uint32_t), c->stream));
+  c->fetchCursor = 0;
+  hipLaunchKernelGGL(k_probe_pack, dim3((n + 255) / 256), dim3(256), 0, c->stream, originDev3, dirDev3, n, c->rayO.p, c->rayD.p, c->live.p);
+  HIPCHK(hipGetLastError());
+  int rc;
+  if ((rc = launchTrace<CLOSEST>(c, n, 0, 0, tmin, tmax)) || (rc = launchTrace<ANYPROBE>(c, n, 0, 0, tmin, tmax)))
+    return rc;
+  hipLaunchKernelGGL(k_probe_unpack, dim3((n + 255) / 256), dim3(256), 0, c->stream, devScene(c), c->hit.p, n, triIdDev, tDev);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 }
