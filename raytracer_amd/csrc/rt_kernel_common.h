@@ -20,6 +20,7 @@ constexpr uint32_t kDone = 0xffffffffu; // `cur`: the ray has no node, leaf or m
 constexpr uint32_t kNone = 0xfffffffeu; // `cur` / `postponed`: empty
 constexpr uint32_t kRefillThreshold = 16; // refill once this many lanes are idle (or no lane is active)
 constexpr uint32_t kMaxRun = 1024;     // most work items one wave is handed (static mode)
+constexpr uint32_t kShadeRun = 1024;   // items a wave shades between two appends to the next depth's slot list (one atomic per run)
 constexpr uint32_t kFetchShards = 8;   // one work counter per XCD label (blockIdx % 8): 8x the atomic rate of one word, L2-local ranges
 constexpr uint32_t kFetchStride = 64;  // counters 256 B apart
 constexpr uint32_t kMaxTraceLaunches = 2 * (64 + 2); // two traversal launches per depth, depth <= kMaxDepthSlots
@@ -72,7 +73,8 @@ struct FrameGeom
   uint32_t tileSize, tilesX, numLocalTiles;
   uint32_t numLocalPixels;  // P = numLocalTiles * tileSize^2
   uint32_t tileShift;       // log2(tileSize); tiles are powers of two so that pixel decoding is shifts and masks
-  uint32_t sampleMagic;     // ceil(2^32 / numLocalTiles) (0 when numLocalTiles == 1): slot -> sample index without a division
+  uint32_t batchSamples;    // S: sample passes in the current launch batch (set per batch by the host)
+  uint32_t batchMagic;      // ceil(2^32 / S) (0 when S == 1): slot -> (micro-block, sample) without a division
   const uint32_t* tileXY;   // device, numLocalTiles entries: x0 | y0 << 16, the tile's first pixel
 };
 
@@ -106,12 +108,24 @@ __device__ __forceinline__ uint32_t xcdRemap(uint32_t b, uint32_t nb)
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-// slot -> (sample index within the batch, local pixel index)
+// Slot layout of a launch batch of S sample passes over P local pixels: the S samples of a 16-pixel micro-block (two rows
+// of an 8x8 pixel block) are adjacent,
+//     slot = ((i >> 4) * S + s) * 16 + (i & 15)        i = local pixel, s = sample index within the batch,
+// so a wave's 64 consecutive slots are 16 neighbouring pixels x 4 samples: rays that walk the same BVH nodes and hit
+// the same triangles.  Node fetches are bound by the rate at which a CU can pull distinct 64-byte lines out of L2
+// (tools/ubench/gather64: 2.5 cycles per line; lanes that want a line another lane of the wave just fetched are nearly
+// free), so the sample-major order of round 1 (slot = s * P + i, one sample per wave) paid for every line S times.
+// slot -> (sample index within the batch, local pixel index); exact while (numSlots / 16) * S < 2^32
 __device__ __forceinline__ void sampleOf(const FrameGeom& g, uint32_t slot, uint32_t& s, uint32_t& i)
 {
-  const uint32_t t = slot >> (2u * g.tileShift); // global tile slot = s * numLocalTiles + local tile
-  s = g.sampleMagic ? __umulhi(t, g.sampleMagic) : t;
-  i = slot - s * g.numLocalPixels;
+  const uint32_t q = slot >> 4;
+  const uint32_t mb = g.batchMagic ? __umulhi(q, g.batchMagic) : q;
+  s = q - mb * g.batchSamples;
+  i = (mb << 4) | (slot & 15u);
+}
+__device__ __forceinline__ uint32_t slotOf(const FrameGeom& g, uint32_t s, uint32_t i)
+{
+  return (((i >> 4) * g.batchSamples + s) << 4) | (i & 15u);
 }
 
 // local pixel index -> image pixel; 8x8 pixel blocks are contiguous so a wave covers a compact footprint

@@ -54,26 +54,39 @@ struct ShadeArgs
   uint32_t aovDepths;
   uint32_t* aovTri;        // [S][aovDepths][P]
   uint8_t* aovShadow;      // [S][aovDepths][P]
-  const uint32_t* list;    // sparse mode: slots alive at `depth` (nullptr = dense)
-  uint32_t* listNext;      // sparse mode: survivors are appended here (count in counters->listCount[depth+1])
+  const uint32_t* list;    // depth >= 1: the slots alive at `depth`, listCount[depth] of them (nullptr at depth 0: every slot)
+  uint32_t* listNext;      // the paths that go on are appended here (count in counters->listCount[depth+1]); nullptr: none kept
 };
 
+// One launch per depth.  SPARSE = false (depth 0): every slot of the batch is an item; SPARSE = true (depth >= 1): the items
+// are the entries of the slot list the previous depth's launch wrote (its length lives in device memory, so the host never
+// has to learn how many paths are still alive).  Paths that go on are appended to the next depth's list: a wave shades a
+// run of kShadeRun consecutive items, keeps the surviving slots in LDS in item order, and publishes them with ONE atomic,
+// so the list keeps the spatial order of the slots (neighbouring entries = neighbouring pixels and samples) and the one
+// counter word sees numItems / 1024 atomics per launch instead of one per wave iteration.
 template <bool SPARSE>
 __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
 {
+  __shared__ uint32_t sKeep[kWavesPerBlock][kShadeRun];
   __shared__ uint32_t sAlive[kWavesPerBlock], sHits[kWavesPerBlock];
   uint32_t nAlive = 0, nHits = 0;
   const uint8_t depthTag = (uint8_t)a.depth;
   const vec3 albedo{0.0f, 1.0f, 0.0f};    // CPUScene.cpp:245
   const vec3 emissive{0.0f, 0.0f, 0.0f};  // CPUScene.cpp:246
   const uint32_t total = SPARSE ? a.counters->listCount[a.depth] : a.numSlots;
-  // every wave runs the same number of iterations so that the sparse append can use wave-wide ballots
-  const uint32_t stride = gridDim.x * kBlock;
-  const uint32_t iters = (total + stride - 1) / stride;
-  for (uint32_t it = 0; it < iters; ++it)
+  const uint32_t lane = laneId(), wv = threadIdx.x >> 6;
+  uint32_t* keep = sKeep[wv];
+  const uint32_t numWaves = gridDim.x * kWavesPerBlock;
+  const uint32_t numRuns = (total + kShadeRun - 1) / kShadeRun;
+  const bool appending = a.finalFold == 0 && a.listNext != nullptr;
+  for (uint32_t run = blockIdx.x * kWavesPerBlock + wv; run < numRuns; run += numWaves)
   {
-    const uint32_t item = it * stride + blockIdx.x * kBlock + threadIdx.x;
-    bool mine = item < total;
+    uint32_t kept = 0; // wave-uniform
+    const uint32_t runBegin = run * kShadeRun, runEnd = min(total, runBegin + kShadeRun);
+    for (uint32_t base = runBegin; base < runEnd; base += 64)
+    {
+    const uint32_t item = base + lane;
+    bool mine = item < runEnd;
     uint32_t p = item;
     if (SPARSE)
     {
@@ -182,19 +195,24 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
         survives = true;
       }
     }
-    if (SPARSE)
+    if (appending)
     {
-      // append the survivors to the next depth's slot list: one atomic per wave, ranks from the ballot
       const uint64_t m = __ballot(survives);
-      if (m)
-      {
-        uint32_t base = 0;
-        if (laneId() == (uint32_t)__ffsll((long long)m) - 1)
-          base = atomicAdd(&a.counters->listCount[a.depth + 1], (uint32_t)__popcll(m));
-        base = __shfl(base, __ffsll((long long)m) - 1);
-        if (survives)
-          a.listNext[base + rankIn(m)] = p;
-      }
+      if (survives)
+        keep[kept + rankIn(m)] = p;
+      kept += (uint32_t)__popcll(m);
+    }
+    }
+    // publish the run's survivors: one atomic, then the LDS copy goes out in item order
+    // (the buffer is written and read by this wave only; LDS operations of one wave complete in order)
+    if (appending && kept)
+    {
+      uint32_t dst = 0;
+      if (lane == 0)
+        dst = atomicAdd(&a.counters->listCount[a.depth + 1], kept);
+      dst = __builtin_amdgcn_readfirstlane(dst);
+      for (uint32_t k = lane; k < kept; k += 64)
+        a.listNext[dst + k] = keep[k];
     }
   }
   // block tallies: one atomic per block and counter
@@ -203,7 +221,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
     nAlive += __shfl_down(nAlive, off);
     nHits += __shfl_down(nHits, off);
   }
-  const uint32_t wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63u) == 0)
   {
     sAlive[wv] = nAlive;
@@ -225,61 +242,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
   }
 }
 
-// dense -> sparse hand-over: collects the slots alive at `depth` into a list (order: ascending slot within a
-// block's 4096-slot span, spans in arrival order).  One atomic per block.
-__global__ __launch_bounds__(kBlock) void k_compact(PathBuffers pb, uint32_t numSlots, uint32_t depth, uint32_t* list, uint32_t capacity,
-                                                    DeviceCounters* counters)
-{
-  __shared__ uint32_t sWave[kWavesPerBlock];
-  __shared__ uint32_t sBase;
-  const uint32_t lane = laneId(), wv = threadIdx.x >> 6;
-  const uint32_t spanBase = blockIdx.x * (kBlock * 16) + threadIdx.x * 16;
-  uint32_t bits = 0, cnt = 0;
-  if (spanBase < numSlots) // numSlots is a multiple of 64, the buffer is padded: the 16-byte load stays in bounds
-  {
-    const uint4 v = *reinterpret_cast<const uint4*>(pb.live + spanBase);
-    const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if (spanBase + k < numSlots && ((wds[k >> 2] >> ((k & 3) * 8)) & 0xffu) == depth)
-      {
-        bits |= 1u << k;
-        cnt++;
-      }
-  }
-  // exclusive prefix of cnt over the wave, then over the block
-  uint32_t incl = cnt;
-  for (int off = 1; off < 64; off <<= 1)
-  {
-    const uint32_t up = __shfl_up(incl, off);
-    if ((int)lane >= off)
-      incl += up;
-  }
-  if (lane == 63)
-    sWave[wv] = incl;
-  __syncthreads();
-  if (threadIdx.x == 0)
-  {
-    uint32_t tot = 0;
-    for (uint32_t k = 0; k < kWavesPerBlock; ++k)
-    {
-      const uint32_t c = sWave[k];
-      sWave[k] = tot;
-      tot += c;
-    }
-    sBase = tot ? atomicAdd(&counters->listCount[depth], tot) : 0u;
-  }
-  __syncthreads();
-  uint32_t dst = sBase + sWave[wv] + (incl - cnt);
-  for (int k = 0; k < 16; ++k)
-    if ((bits >> k) & 1u)
-    {
-      if (dst < capacity)
-        list[dst] = spanBase + k;
-      dst++;
-    }
-}
-
 // accumulator[pix] += radiance / float(N), sample passes in ascending order (CPURenderer.cpp:197)
 // `fresh` = first batch of a frame: the accumulator is taken as zero instead of being loaded (saves clearing it beforehand)
 __global__ __launch_bounds__(kBlock) void k_accumulate(FrameGeom g, PathBuffers pb, float* acc, uint32_t numBatchSamples, uint32_t fresh)
@@ -292,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameGeom g, PathBuffers 
   const float n = float(g.numSamples);
   for (uint32_t s = 0; s < numBatchSamples; ++s)
   {
-    const size_t p = (size_t)s * g.numLocalPixels + i;
+    const size_t p = slotOf(g, s, i);
     // kDeadZero: the sample's radiance is exactly +0 (primary miss) -> adding 0/N leaves the sum unchanged
     if (pb.live[p] != kDead)
       continue;

@@ -17,7 +17,7 @@ struct TraceArgs
   const uint32_t* list;      // sparse: work item -> slot; nullptr in dense mode
   const uint32_t* listCount; // sparse: number of work items (device memory)
   uint32_t runLen;           // static mode: work items per wave (multiple of 64, <= kMaxRun)
-  uint32_t chunkLen;         // dynamic mode: work items per fetch (multiple of 64)
+  uint32_t chunkLen;         // dynamic mode: work items per fetch (multiple of 64); 0 = derive it from the list length on the device
   uint32_t refillAt;         // idle lanes that trigger a refill from the work list
   uint32_t leafTrigger;      // lanes waiting on a leaf that trigger a leaf step
   uint32_t stealSpans;       // spans a wave may pull chunks from: its own first, then its neighbours'
@@ -62,7 +62,16 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
   uint32_t runNext = dynamic ? 0u : min(total, wid * a.runLen);
   uint32_t runEnd = dynamic ? 0u : min(total, runNext + a.runLen);
   const uint32_t shard = blockIdx.x % kFetchShards;
-  const uint32_t chunksPerShard = dynamic ? ((total + kFetchShards - 1) / kFetchShards + a.chunkLen - 1) / a.chunkLen : 0u;
+  // list launches: the host does not know how many paths are alive, so the chunk size is derived here from the list's
+  // length (every resident wave fetches ~8 times when there is that much work, as dynamicGeometry does for dense launches)
+  uint32_t chunkLen = a.chunkLen;
+  if (dynamic && chunkLen == 0)
+  {
+    const uint32_t waves = gridDim.x * kWavesPerBlock;
+    const uint32_t cl = (((total + waves * 8u - 1) / (waves * 8u)) + 63u) & ~63u;
+    chunkLen = max(64u, min(cl, 4u * kChunk));
+  }
+  const uint32_t chunksPerShard = dynamic ? ((total + kFetchShards - 1) / kFetchShards + chunkLen - 1) / chunkLen : 0u;
   bool exhausted = !dynamic; // dynamic mode: no more chunks anywhere
   uint32_t shardsDone = 0;   // spans found empty so far: the wave's own first, then its neighbours' (work stealing)
   // pulls the next chunk into [runNext, runEnd): from this wave's own span while it lasts, then from the other spans
@@ -74,11 +83,11 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
     if (lane == 0)
       c = atomicAdd(a.fetch + sh * kFetchStride, 1u);
     c = __builtin_amdgcn_readfirstlane(c);
-    const uint32_t base = (sh * chunksPerShard + c) * a.chunkLen;
+    const uint32_t base = (sh * chunksPerShard + c) * chunkLen;
     if (c < chunksPerShard && base < total)
     {
       runNext = base;
-      runEnd = min(total, base + a.chunkLen);
+      runEnd = min(total, base + chunkLen);
     }
     else if (++shardsDone >= a.stealSpans) // this span is empty: the next call tries the next one
       exhausted = true;

@@ -175,9 +175,8 @@ struct rthip_ctx
   DevBuf<uint32_t> spill;
   DevBuf<uint32_t> fetch;        // [batch counters (kCounterWords) | work-fetch counters]: everything a batch zeroes, one memset
   DevBuf<uint32_t> spill2;       // stack spill area of launches on stream2
-  DevBuf<uint32_t> listA, listB; // sparse-mode slot lists (even / odd depth)
+  DevBuf<uint32_t> listA, listB; // slot lists of the paths alive at even / odd depths (one entry per slot of the batch at most)
   uint32_t spillCap = 1;         // per-lane spill entries the uploaded BVH can need
-  uint32_t sparseCap = 0;        // capacity of listA / listB
   uint32_t tuneBlocks = 6;
   uint32_t overlapShadow = 1;    // run a depth's shadow and closest-hit launches on two streams (their tails overlap)
   uint32_t tuneSteal = 1; // spans a wave may pull chunks from (1 = its own only; stealing measured +4% on the 1M soup, -4% on the bunny: off)
@@ -214,7 +213,8 @@ struct rthip_ctx
   hipStream_t lastAccStream = nullptr;
   bool altPending = false;       // work may be in flight on the second slot's stream that the main stream has not joined
   uint32_t frameParity = 0;      // camera constants and counter totals are double-buffered per frame (frames overlap)
-  uint32_t pipelineBatches = 2;  // pieces a call's passes are split into when the second slot is used (depth cap 1, >= 2 passes); 0 = off
+  uint32_t pipelineBatches = 2;  // 2: batches alternate between the two slots (two in flight); 0 = one slot only
+  uint32_t batchToggle = 0;      // which slot the next batch goes to (alternates across calls and frames)
 };
 
 namespace
@@ -333,23 +333,23 @@ int ensurePathBuffers(rthip_ctx* c, size_t numSlots)
     return rc;
   if ((rc = c->fetch.ensure(kCounterWords + (size_t)kMaxTraceLaunches * kFetchShards * kFetchStride)))
     return rc;
-  c->sparseCap = (uint32_t)std::max<size_t>(4096, numSlots / 32);
-  if ((rc = c->listA.ensure(c->sparseCap)) || (rc = c->listB.ensure(c->sparseCap)))
+  if ((rc = c->listA.ensure(numSlots)) || (rc = c->listB.ensure(numSlots)))
     return rc;
   return 0;
 }
 
-// list == nullptr: dense launch over all numSlots slots; otherwise sparse launch over the device-side list whose
-// length is at most `bound`
+// list == nullptr: dense launch over all numSlots slots; otherwise a launch over the device-side slot list of `depth`,
+// whose length (counters->listCount[depth]) only the device knows: the whole persistent grid is launched and sizes its
+// chunks from that length
 template <int MODE>
 int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBegin, float tmin, float tmax, const uint32_t* list = nullptr,
-                uint32_t bound = 0, bool foldFinal = false, bool sideStream = false)
+                bool foldFinal = false, bool sideStream = false, const FrameGeom* batchGeom = nullptr)
 {
   TraceArgs a;
   a.scene = devScene(c);
   a.pb = pathBuffers(c);
   a.lights = c->lights.p;
-  a.geom = c->geom;
+  a.geom = batchGeom ? *batchGeom : c->geom;
   a.cam = frameCamera(c);
   a.sampBegin = sampBegin;
   a.numSlots = numSlots;
@@ -376,7 +376,13 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
     staticGeometry(numSlots, blocks, a.runLen);
   else
   {
-    dynamicGeometry(c, list ? bound : numSlots, blocks, a.chunkLen);
+    if (list)
+    {
+      blocks = c->traceBlocks;
+      a.chunkLen = 0;
+    }
+    else
+      dynamicGeometry(c, numSlots, blocks, a.chunkLen);
     if (c->fetchCursor >= kMaxTraceLaunches)
       return RTHIP_E_LIMIT;
     a.fetch = fetchBase(c) + (size_t)(c->fetchCursor++) * kFetchShards * kFetchStride;
@@ -392,12 +398,18 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   return (int)hipGetLastError();
 }
 
-// one batch of `count` sample passes starting at sampBegin
+// One batch of `count` sample passes starting at sampBegin.  Nothing here waits for the device: from depth 1 on every
+// launch works on the slot list the previous depth's k_shade wrote, whose length stays in device memory, so all depths up
+// to the cap are queued unconditionally (a launch whose list is empty returns at once) and batches and frames can overlap.
 int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, hipEvent_t accumulateAfter = nullptr)
 {
   const uint32_t P = c->geom.numLocalPixels;
   const uint32_t numSlots = P * count;
-  const uint32_t shadeBlocksDense = std::max(1u, std::min((numSlots + kBlock - 1) / kBlock, (uint32_t)c->numCUs * 8u));
+  FrameGeom g = c->geom; // + this batch's slot layout (see sampleOf)
+  g.batchSamples = count;
+  g.batchMagic = count > 1 ? (uint32_t)(((1ull << 32) + count - 1) / count) : 0u;
+  const uint32_t shadeBlocks = std::max(1u, std::min((numSlots + kShadeRun * kWavesPerBlock - 1) / (kShadeRun * kWavesPerBlock), (uint32_t)c->numCUs * 8u));
+  HIPCHK(hipStreamWaitEvent(c->stream, c->evFrame, 0)); // the frame prologue (k_camera) may have run on the other slot's stream
   HIPCHK(hipMemsetAsync(c->fetch.p, 0, c->fetch.n * sizeof(uint32_t), c->stream)); // batch counters + work-fetch counters
   c->fetchCursor = 0;
   if (c->aovDepths)
@@ -409,13 +421,13 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, hipEvent_t acc
   if (!fused)
   {
     KernelTimer kt(c, 0);
-    hipLaunchKernelGGL(k_generate, dim3((numSlots + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->geom, frameCamera(c), pathBuffers(c),
-                       sampBegin, numSlots);
+    hipLaunchKernelGGL(k_generate, dim3((numSlots + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, g, frameCamera(c), pathBuffers(c), sampBegin,
+                       numSlots);
     HIPCHK(hipGetLastError());
   }
   const bool haveDirLights = c->hostLights.numDir > 0;
   ShadeArgs sa;
-  sa.g = c->geom;
+  sa.g = g;
   sa.scene = devScene(c);
   sa.pb = pathBuffers(c);
   sa.lights = c->lights.p;
@@ -429,12 +441,11 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, hipEvent_t acc
   sa.aovTri = c->aovTri.p;
   sa.aovShadow = c->aovShadow.p;
   const float tmin = 1e-4f, tmax = 1e20f; // CPURenderer.cpp:194, CPUScene.cpp:34 (double literals narrowed to float)
-  bool sparse = false;
-  uint32_t bound = numSlots; // upper bound of the paths alive at the current depth
   for (uint32_t d = 0;; ++d)
   {
     const bool last = d == c->maxDepth;
-    const uint32_t* list = sparse ? ((d & 1u) ? c->listB.p : c->listA.p) : nullptr;
+    // list of the paths alive at depth d (written by k_shade(d-1)); depth 0 is every slot
+    const uint32_t* list = d == 0 ? nullptr : ((d & 1u) ? c->listB.p : c->listA.p);
     uint32_t* listNext = (d & 1u) ? c->listA.p : c->listB.p;
     int rc;
     // shadow rays of the hits of depth d-1; at the last depth the same launch also folds the lights and finishes the paths
@@ -447,7 +458,7 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, hipEvent_t acc
       HIPCHK(hipEventRecord(c->evFork, c->stream));
       HIPCHK(hipStreamWaitEvent(c->stream2, c->evFork, 0));
     }
-    if (d > 0 && haveDirLights && (rc = launchTrace<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, bound, last, side)))
+    if (d > 0 && haveDirLights && (rc = launchTrace<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g)))
       return rc;
     if (side)
     {
@@ -460,11 +471,11 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, hipEvent_t acc
       // coherent primary rays over a scene of a few nodes cost the same everywhere: static 64-slot groups, no atomics;
       // otherwise traversal length varies pixel to pixel and lanes are refilled from dynamically fetched chunks
       if (d == 0 && fused && c->info.numNodes <= 64)
-        rc = launchTrace<PRIMARY_GROUP>(c, numSlots, 0, sampBegin, tmin, tmax);
+        rc = launchTrace<PRIMARY_GROUP>(c, numSlots, 0, sampBegin, tmin, tmax, nullptr, false, false, &g);
       else if (d == 0 && fused)
-        rc = launchTrace<PRIMARY>(c, numSlots, 0, sampBegin, tmin, tmax);
+        rc = launchTrace<PRIMARY>(c, numSlots, 0, sampBegin, tmin, tmax, nullptr, false, false, &g);
       else
-        rc = launchTrace<CLOSEST>(c, numSlots, d, sampBegin, tmin, tmax, list, bound);
+        rc = launchTrace<CLOSEST>(c, numSlots, d, sampBegin, tmin, tmax, list, false, false, &g);
       if (rc)
         return rc;
     }
@@ -473,45 +484,23 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, hipEvent_t acc
     sa.depth = d;
     sa.finalFold = last ? 1u : 0u;
     sa.list = list;
-    sa.listNext = listNext;
+    sa.listNext = last ? nullptr : listNext;
     {
       KernelTimer kt(c, 2);
-      if (sparse)
-      {
-        const uint32_t blocks = std::max(1u, std::min((bound + kBlock - 1) / kBlock, (uint32_t)c->numCUs * 8u));
-        hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(kBlock), 0, c->stream, sa);
-      }
+      if (d > 0)
+        hipLaunchKernelGGL(k_shade<true>, dim3(shadeBlocks), dim3(kBlock), 0, c->stream, sa);
       else
-        hipLaunchKernelGGL(k_shade<false>, dim3(shadeBlocksDense), dim3(kBlock), 0, c->stream, sa);
+        hipLaunchKernelGGL(k_shade<false>, dim3(shadeBlocks), dim3(kBlock), 0, c->stream, sa);
       HIPCHK(hipGetLastError());
     }
     if (last)
       break;
-    if (!sparse && d + 1 < c->maxDepth)
-    {
-      // how many paths go on?  stop when none do; switch to slot lists when few do (open scenes lose most paths
-      // within a bounce or two, and scanning every slot's liveness byte for a handful of paths is wasted work)
-      unsigned long long alive = 0;
-      HIPCHK(hipMemcpyAsync(&alive, &batchCounters(c)->alive[d + 1], sizeof(alive), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
-      if (alive == 0)
-        break;
-      bound = (uint32_t)alive;
-      if (alive <= c->sparseCap / 2)
-      {
-        KernelTimer kt(c, 5);
-        hipLaunchKernelGGL(k_compact, dim3((numSlots + kBlock * 16 - 1) / (kBlock * 16)), dim3(kBlock), 0, c->stream, pathBuffers(c), numSlots,
-                           d + 1, listNext, c->sparseCap, batchCounters(c));
-        HIPCHK(hipGetLastError());
-        sparse = true;
-      }
-    }
   }
   if (accumulateAfter) // the previous batch ran on the other slot: per-pixel accumulation stays in sample order
     HIPCHK(hipStreamWaitEvent(c->stream, accumulateAfter, 0));
   {
     KernelTimer kt(c, 4);
-    hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->geom, pathBuffers(c), c->acc.p, count, c->accFresh ? 1u : 0u);
+    hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, g, pathBuffers(c), c->acc.p, count, c->accFresh ? 1u : 0u);
     c->accFresh = false;
     HIPCHK(hipGetLastError());
   }
@@ -531,30 +520,27 @@ int renderPasses(rthip_ctx* c, uint32_t sampBegin, uint32_t count, bool sync)
   if (count == 0 || sampBegin + count > c->geom.numSamples)
     return RTHIP_E_ARG;
   HIPCHK(hipSetDevice(c->device));
-  // Two batches in flight (see rthip_ctx::Slot) when a batch needs no host round trip: the passes are split in two pieces
-  // (more pieces measured slower: 3 -> -13 %, 8 -> -33 %) that alternate between the slots.  Nothing joins the slots at
-  // the end of the call: the next frame's first piece starts while this frame's second piece is still shading, and
-  // only the accumulate kernels are chained (per-pixel sums stay in sample order).
-  const bool pipelined = c->pipelineBatches && c->maxDepth == 1 && c->aovDepths == 0 && count >= 2;
+  // Two batches in flight (see rthip_ctx::Slot): no batch needs a host round trip, so batches alternate between two sets of
+  // path buffers and streams -- across calls and frames too -- and the ramp and tail of one batch's launches are filled by
+  // the other's.  A call with several passes is split in two pieces (more pieces measured slower in round 1).  Nothing
+  // joins the slots at the end of the call; only the accumulate kernels are chained (per-pixel sums stay in sample order).
+  const bool pipelined = c->pipelineBatches && c->aovDepths == 0;
   uint32_t piece = c->batchCap;
   if (pipelined)
   {
-    piece = std::min(c->batchCap, (count + 1) / 2);
-    const uint32_t keepSparseCap = c->sparseCap;
+    if (count >= 2)
+      piece = std::min(c->batchCap, (count + 1) / 2);
     swapSlot(c);
-    int rc = ensurePathBuffers(c, (size_t)c->geom.numLocalPixels * piece);
+    int rc = ensurePathBuffers(c, (size_t)c->geom.numLocalPixels * std::min(piece, count));
     swapSlot(c);
-    c->sparseCap = keepSparseCap;
     if (rc)
       return rc;
-    HIPCHK(hipEventRecord(c->evFrame, c->stream));              // the frame prologue (and everything before it) ...
-    HIPCHK(hipStreamWaitEvent(c->alt.stream, c->evFrame, 0));   // ... precedes the second slot's work
   }
   uint32_t done = 0;
-  for (uint32_t k = 0; done < count; ++k)
+  while (done < count)
   {
     const uint32_t n = std::min(piece, count - done);
-    const bool useAlt = pipelined && (k & 1u);
+    const bool useAlt = pipelined && (c->batchToggle++ & 1u);
     if (useAlt)
       swapSlot(c);
     hipEvent_t after = (c->lastAcc && c->lastAccStream != c->stream) ? c->lastAcc : nullptr;
@@ -723,14 +709,30 @@ int rthip_upload_scene(rthip_ctx* c, const rtflat_info* info, const rtflat_model
         return RTHIP_E_ARG;
     }
   }
-  for (uint32_t k = 0; k < info->numNodes; ++k)
-    for (uint32_t ref : nodes[k].child)
-    {
-      if (ref == RTFLAT_INVALID)
-        continue; // unused slot (its box is inverted)
-      if (rtflat_is_leaf(ref) ? (rtflat_leaf_first(ref) + rtflat_leaf_count(ref) > info->numTris) : (ref >= info->numNodes || ref <= k))
-        return RTHIP_E_ARG; // children follow their parent (pre-order): no cycles
-    }
+  // children follow their parent (pre-order), so one ascending sweep both rules out cycles and measures the deepest chain
+  // of 4-wide nodes: the spill stack is sized from what the arrays really hold, not from what the caller says
+  uint32_t deepest = 1;
+  {
+    std::vector<uint8_t> level(info->numNodes, 1);
+    for (uint32_t k = 0; k < info->numNodes; ++k)
+      for (uint32_t ref : nodes[k].child)
+      {
+        if (ref == RTFLAT_INVALID)
+          continue; // unused slot (its box is inverted)
+        if (rtflat_is_leaf(ref) ? (rtflat_leaf_first(ref) + rtflat_leaf_count(ref) > info->numTris) : (ref >= info->numNodes || ref <= k))
+          return RTHIP_E_ARG;
+        if (!rtflat_is_leaf(ref))
+        {
+          if (level[k] >= 250)
+            return RTHIP_E_LIMIT;
+          level[ref] = std::max<uint8_t>(level[ref], (uint8_t)(level[k] + 1));
+          deepest = std::max<uint32_t>(deepest, level[ref]);
+        }
+      }
+  }
+  deepest = std::max(deepest, info->maxDepthBlas);
+  if (3 * deepest + 2 > kMaxStack)
+    return RTHIP_E_LIMIT;
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->alt.stream)); // frames still in flight on either slot read the old scene
   c->altPending = false;
@@ -752,7 +754,8 @@ int rthip_upload_scene(rthip_ctx* c, const rtflat_info* info, const rtflat_model
     L.point[i] = pointLights[i];
   HIPCHK(hipMemcpy(c->lights.p, &L, sizeof(L), hipMemcpyHostToDevice));
   c->info = *info;
-  c->spillCap = 3 * info->maxDepthBlas + 2 > kStackLds ? 3 * info->maxDepthBlas + 2 - kStackLds : 1u;
+  c->info.maxDepthBlas = deepest;
+  c->spillCap = 3 * deepest + 2 > kStackLds ? 3 * deepest + 2 - kStackLds : 1u;
   c->spill.release(); // sized per scene in ensurePathBuffers
   c->haveScene = true;
   c->haveFrame = false;
@@ -782,82 +785,104 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
       return RTHIP_E_BOUNDS;
   }
   HIPCHK(hipSetDevice(c->device));
-  // No host synchronisation here: a frame is enqueued behind the previous one on the context's stream, so a caller that
+  // No host synchronisation here: a frame is enqueued behind the previous one on the context's streams, so a caller that
   // uses rthip_enqueue_passes keeps the GPU busy across frames (buffers only ever grow, and growing one synchronises).
+  // Everything is validated and sized into locals first; the context's frame state changes only once nothing can fail.
   const uint32_t tilesX = (f->width + ts - 1) / ts, tilesY = (f->height + ts - 1) / ts;
   FrameGeom g{};
   g.width = f->width, g.height = f->height, g.numSamples = f->numSamples;
   g.tileSize = ts, g.tilesX = tilesX;
-  c->hostTileIds.clear();
+  std::vector<uint32_t> tileIds;
   if (f->numTiles)
   {
     if (!f->tileIds)
       return RTHIP_E_ARG;
+    tileIds.reserve(f->numTiles);
     for (uint32_t k = 0; k < f->numTiles; ++k)
     {
       if (f->tileIds[k] >= tilesX * tilesY)
         return RTHIP_E_ARG;
-      c->hostTileIds.push_back(f->tileIds[k]);
+      tileIds.push_back(f->tileIds[k]);
     }
   }
   else
+  {
+    tileIds.resize((size_t)tilesX * tilesY);
     for (uint32_t k = 0; k < tilesX * tilesY; ++k)
-      c->hostTileIds.push_back(k);
-  g.numLocalTiles = (uint32_t)c->hostTileIds.size();
+      tileIds[k] = k;
+  }
+  g.numLocalTiles = (uint32_t)tileIds.size();
   const uint64_t P64 = (uint64_t)g.numLocalTiles * ts * ts;
   if (P64 == 0 || P64 > (1ull << 30))
     return RTHIP_E_LIMIT;
   g.numLocalPixels = (uint32_t)P64;
+  const uint32_t aovDepths = std::min(f->aovDepths, f->maxDepth);
+  // sample passes per launch batch: as many as fit in 2^25 paths (about 100 B of state each)
+  const uint64_t pathCap = 1ull << 25;
+  uint32_t batchCap = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(f->numSamples, pathCap / P64));
+  if (aovDepths)
+    batchCap = std::min(batchCap, 4u);
+  // sampleOf's multiply-high division is exact while (slots / 16) * batch < 2^32
+  while (batchCap > 1 && (P64 * batchCap / 16) * batchCap >= (1ull << 32))
+    batchCap--;
+  const size_t numSlots = (size_t)P64 * batchCap;
   int rc;
-  {
-    const uint32_t* before = c->tileIds.p;
-    if ((rc = c->tileIds.ensure(g.numLocalTiles)))
-      return rc;
-    if (c->tileIds.p != before)
-      c->hostTileXY.clear();
-  }
+  // the previous frame may still be running on either slot: its kernels read the tile table and, when a buffer has to grow,
+  // the memory about to be freed
+  auto quiesce = [&]() -> int {
+    HIPCHK(hipStreamSynchronize(c->alt.stream));
+    HIPCHK(hipStreamSynchronize(c->alt.stream2));
+    HIPCHK(hipStreamSynchronize(c->stream2));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->altPending = false;
+    return 0;
+  };
+  const bool grows = numSlots > c->rayO.n || P64 * 3 > c->acc.n || g.numLocalTiles > c->tileIds.n || !c->camConsts.p || !c->totals.p ||
+                     (aovDepths && numSlots * aovDepths > c->aovTri.n);
+  if (grows && (rc = quiesce()))
+    return rc;
+  if ((rc = c->tileIds.ensure(g.numLocalTiles)) || (rc = ensurePathBuffers(c, numSlots)) || (rc = c->acc.ensure(P64 * 3)) ||
+      (rc = c->img.ensure(P64 * 3)) || (rc = c->camConsts.ensure(2)) || (rc = c->totals.ensure(2)))
+    return rc;
+  if (aovDepths && ((rc = c->aovTri.ensure(numSlots * aovDepths)) || (rc = c->aovShadow.ensure(numSlots * aovDepths))))
+    return rc;
   {
     std::vector<uint32_t> xy(g.numLocalTiles);
     for (uint32_t k = 0; k < g.numLocalTiles; ++k)
-      xy[k] = ((c->hostTileIds[k] % tilesX) * ts) | (((c->hostTileIds[k] / tilesX) * ts) << 16);
-    if (xy != c->hostTileXY) // frames of one animation keep their tiling: upload the table only when it changes
+      xy[k] = ((tileIds[k] % tilesX) * ts) | (((tileIds[k] / tilesX) * ts) << 16);
+    if (grows || xy != c->hostTileXY) // frames of one animation keep their tiling: upload the table only when it changes
     {
-      HIPCHK(hipStreamSynchronize(c->alt.stream)); // kernels of the previous frame (either slot) may still read the old table
-      HIPCHK(hipStreamSynchronize(c->stream));
+      if (!grows && (rc = quiesce()))
+        return rc;
+      c->hostTileXY.clear(); // (stays empty if the copy fails: the next frame uploads again)
       HIPCHK(hipMemcpy(c->tileIds.p, xy.data(), sizeof(uint32_t) * g.numLocalTiles, hipMemcpyHostToDevice));
       c->hostTileXY.swap(xy);
     }
   }
+  // ---- commit
   g.tileXY = c->tileIds.p;
   g.tileShift = (uint32_t)__builtin_ctz(ts);
-  g.sampleMagic = g.numLocalTiles > 1 ? (uint32_t)(((1ull << 32) + g.numLocalTiles - 1) / g.numLocalTiles) : 0u;
+  g.batchSamples = 1, g.batchMagic = 0; // set per batch (renderBatch)
+  c->hostTileIds.swap(tileIds);
   c->geom = g;
   c->camera = *camera;
   c->maxDepth = f->maxDepth;
-  c->aovDepths = std::min(f->aovDepths, f->maxDepth);
-  // sample passes per launch batch: as many as fit in 2^25 paths (about 90 B of state each)
-  const uint64_t pathCap = 1ull << 25;
-  c->batchCap = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(f->numSamples, pathCap / P64));
-  if (c->aovDepths)
-    c->batchCap = std::min(c->batchCap, 4u);
-  // sampleOf's multiply-high division is exact while (batch * tiles) * tiles < 2^32
-  while (c->batchCap > 1 && (uint64_t)c->batchCap * g.numLocalTiles * g.numLocalTiles >= (1ull << 32))
-    c->batchCap--;
-  if ((uint64_t)c->batchCap * g.numLocalTiles * g.numLocalTiles >= (1ull << 32))
-    return RTHIP_E_LIMIT;
-  const size_t numSlots = (size_t)P64 * c->batchCap;
-  if ((rc = ensurePathBuffers(c, numSlots)) || (rc = c->acc.ensure(P64 * 3)) || (rc = c->img.ensure(P64 * 3)) || (rc = c->camConsts.ensure(2)) ||
-      (rc = c->totals.ensure(2)))
-    return rc;
-  if (c->aovDepths)
-  {
-    if ((rc = c->aovTri.ensure(numSlots * c->aovDepths)) || (rc = c->aovShadow.ensure(numSlots * c->aovDepths)))
-      return rc;
-  }
+  c->aovDepths = aovDepths;
+  c->batchCap = batchCap;
   c->accFresh = true; // CPURenderer.cpp:142-143: the clear is folded into the first k_accumulate (or done on a read before it)
-  c->frameParity ^= 1u; // the previous frame's second slot may still be reading its camera and folding its totals
-  hipLaunchKernelGGL(k_camera, dim3(1), dim3(64), 0, c->stream, *camera, frameCamera(c), frameTotals(c));
+  // Camera constants and counter totals are double-buffered per frame: at most two frames are in flight (one per slot; a
+  // third queues behind the first on that slot's stream).  The prologue kernel goes to the stream the frame's first batch
+  // will use, so a one-batch frame on one slot does not wait for the previous frame on the other; every batch of the frame
+  // waits for evFrame.  A frame that never rendered keeps its parity (its buffers are nobody else's).
+  if (c->renderedAny || !c->haveFrame)
+    c->frameParity ^= 1u;
+  const bool firstOnAlt = c->pipelineBatches && aovDepths == 0 && (c->batchToggle & 1u);
+  hipStream_t prologue = firstOnAlt ? c->alt.stream : c->stream;
+  hipLaunchKernelGGL(k_camera, dim3(1), dim3(64), 0, prologue, *camera, frameCamera(c), frameTotals(c));
   HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(c->evFrame, prologue));
+  if (firstOnAlt)
+    c->altPending = true;
   c->renderedAny = false;
   c->haveFrame = true;
   return 0;
