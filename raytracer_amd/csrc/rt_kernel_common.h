@@ -73,8 +73,12 @@ struct FrameGeom
   uint32_t tileSize, tilesX, numLocalTiles;
   uint32_t numLocalPixels;  // P = numLocalTiles * tileSize^2
   uint32_t tileShift;       // log2(tileSize); tiles are powers of two so that pixel decoding is shifts and masks
-  uint32_t batchSamples;    // S: sample passes in the current launch batch (set per batch by the host)
-  uint32_t batchMagic;      // ceil(2^32 / S) (0 when S == 1): slot -> (micro-block, sample) without a division
+  // the current launch batch (set per batch by the host): S sample passes over the local pixels [batchPixelBase,
+  // batchPixelBase + batchPixels), a whole number of tiles
+  uint32_t batchSamples;    // S
+  uint32_t batchLg;         // log2 of the pixels per micro-block (see sampleOf)
+  uint32_t batchPixelBase, batchPixels;
+  uint64_t batchMagic;      // ceil(2^64 / S) (0 when S == 1): slot -> (micro-block, sample) without a division
   const uint32_t* tileXY;   // device, numLocalTiles entries: x0 | y0 << 16, the tile's first pixel
 };
 
@@ -108,24 +112,26 @@ __device__ __forceinline__ uint32_t xcdRemap(uint32_t b, uint32_t nb)
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-// Slot layout of a launch batch of S sample passes over P local pixels: the S samples of a 16-pixel micro-block (two rows
-// of an 8x8 pixel block) are adjacent,
-//     slot = ((i >> 4) * S + s) * 16 + (i & 15)        i = local pixel, s = sample index within the batch,
-// so a wave's 64 consecutive slots are 16 neighbouring pixels x 4 samples: rays that walk the same BVH nodes and hit
-// the same triangles.  Node fetches are bound by the rate at which a CU can pull distinct 64-byte lines out of L2
-// (tools/ubench/gather64: 2.5 cycles per line; lanes that want a line another lane of the wave just fetched are nearly
-// free), so the sample-major order of round 1 (slot = s * P + i, one sample per wave) paid for every line S times.
-// slot -> (sample index within the batch, local pixel index); exact while (numSlots / 16) * S < 2^32
+// Slot layout of a launch batch (S sample passes over a range of the local pixels): the S samples of a micro-block of
+// 2^lg consecutive pixels are adjacent,
+//     slot = ((j >> lg) * S + s) << lg | (j & (2^lg - 1))      j = pixel index within the batch, s = sample index,
+// and the host picks 2^lg = 64 / S (S >= 64: one pixel), so a wave's 64 consecutive slots are as few pixels with as many
+// samples each as the batch allows: rays that walk the same BVH nodes and hit the same triangles.  Node fetches are bound
+// by the rate at which a CU pulls DISTINCT 64-byte lines out of L2 (tools/ubench/gather64: 2.5 cycles per line, 11 when
+// it misses L2; lanes that want a line another lane of the wave just fetched cost 0.4), so the sample-major order of
+// round 1 (slot = s * P + i, one sample per wave) paid for every line S times.
+// slot -> (sample index within the batch, local pixel index of the frame)
 __device__ __forceinline__ void sampleOf(const FrameGeom& g, uint32_t slot, uint32_t& s, uint32_t& i)
 {
-  const uint32_t q = slot >> 4;
-  const uint32_t mb = g.batchMagic ? __umulhi(q, g.batchMagic) : q;
+  const uint32_t q = slot >> g.batchLg;
+  const uint32_t mb = g.batchMagic ? (uint32_t)__umul64hi((uint64_t)q, g.batchMagic) : q; // q / S, exact for every 32-bit q
   s = q - mb * g.batchSamples;
-  i = (mb << 4) | (slot & 15u);
+  i = g.batchPixelBase + ((mb << g.batchLg) | (slot & ((1u << g.batchLg) - 1u)));
 }
-__device__ __forceinline__ uint32_t slotOf(const FrameGeom& g, uint32_t s, uint32_t i)
+// (sample index within the batch, pixel index within the batch) -> slot
+__device__ __forceinline__ uint32_t slotOf(const FrameGeom& g, uint32_t s, uint32_t j)
 {
-  return (((i >> 4) * g.batchSamples + s) << 4) | (i & 15u);
+  return (((j >> g.batchLg) * g.batchSamples + s) << g.batchLg) | (j & ((1u << g.batchLg) - 1u));
 }
 
 // local pixel index -> image pixel; 8x8 pixel blocks are contiguous so a wave covers a compact footprint

@@ -242,25 +242,26 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
   }
 }
 
-// accumulator[pix] += radiance / float(N), sample passes in ascending order (CPURenderer.cpp:197)
-// `fresh` = first batch of a frame: the accumulator is taken as zero instead of being loaded (saves clearing it beforehand)
+// accumulator[pix] += radiance / float(N), sample passes in ascending order (CPURenderer.cpp:197), for the pixels of the batch
+// `fresh` = first render call of a frame: the accumulator is taken as zero instead of being loaded (saves clearing it beforehand)
 __global__ __launch_bounds__(kBlock) void k_accumulate(FrameGeom g, PathBuffers pb, float* acc, uint32_t numBatchSamples, uint32_t fresh)
 {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= g.numLocalPixels)
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= g.batchPixels)
     return;
+  const size_t i = (size_t)g.batchPixelBase + j;
   float r = 0, gg = 0, b = 0;
   bool loaded = fresh != 0; // 0 + x == x and 0 + 0 == +0: starting from zero is what the cleared accumulator would give
   const float n = float(g.numSamples);
   for (uint32_t s = 0; s < numBatchSamples; ++s)
   {
-    const size_t p = slotOf(g, s, i);
+    const size_t p = slotOf(g, s, j);
     // kDeadZero: the sample's radiance is exactly +0 (primary miss) -> adding 0/N leaves the sum unchanged
     if (pb.live[p] != kDead)
       continue;
     if (!loaded)
     {
-      r = acc[3 * (size_t)i], gg = acc[3 * (size_t)i + 1], b = acc[3 * (size_t)i + 2];
+      r = acc[3 * i], gg = acc[3 * i + 1], b = acc[3 * i + 2];
       loaded = true;
     }
     const float4 v = pb.s0[p];
@@ -270,9 +271,9 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameGeom g, PathBuffers 
   }
   if (loaded)
   {
-    acc[3 * (size_t)i] = r;
-    acc[3 * (size_t)i + 1] = gg;
-    acc[3 * (size_t)i + 2] = b;
+    acc[3 * i] = r;
+    acc[3 * i + 1] = gg;
+    acc[3 * i + 2] = b;
   }
 }
 

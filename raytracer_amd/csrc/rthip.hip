@@ -160,7 +160,8 @@ struct rthip_ctx
   rthip_camera camera{};
   FrameGeom geom{};
   uint32_t maxDepth = 12, aovDepths = 0;
-  uint32_t batchCap = 1; // sample passes per launch batch
+  uint64_t pathCap = 1ull << 27; // most paths (slots) a launch batch may hold: about 80 B of state each, per slot set
+  int groupLg = -1;              // log2 pixels per micro-block of the slot layout (-1: 64 / samples of the batch, see sampleOf)
   std::vector<uint32_t> hostTileIds, hostTileXY;
   DevBuf<uint32_t> tileIds;
   DevBuf<CameraConsts> camConsts;
@@ -215,6 +216,7 @@ struct rthip_ctx
   uint32_t frameParity = 0;      // camera constants and counter totals are double-buffered per frame (frames overlap)
   uint32_t pipelineBatches = 2;  // 2: batches alternate between the two slots (two in flight); 0 = one slot only
   uint32_t batchToggle = 0;      // which slot the next batch goes to (alternates across calls and frames)
+  bool framePipelined = false;   // decided by rthip_begin (both slots sized for the frame's batches)
 };
 
 namespace
@@ -401,13 +403,24 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
 // One batch of `count` sample passes starting at sampBegin.  Nothing here waits for the device: from depth 1 on every
 // launch works on the slot list the previous depth's k_shade wrote, whose length stays in device memory, so all depths up
 // to the cap are queued unconditionally (a launch whose list is empty returns at once) and batches and frames can overlap.
-int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, hipEvent_t accumulateAfter = nullptr)
+int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, uint32_t tileBegin, uint32_t tileCount, bool fresh, hipEvent_t accumulateAfter = nullptr)
 {
-  const uint32_t P = c->geom.numLocalPixels;
-  const uint32_t numSlots = P * count;
-  FrameGeom g = c->geom; // + this batch's slot layout (see sampleOf)
+  const uint32_t P = c->geom.numLocalPixels; // of the frame (AOV arrays are indexed by it)
+  const uint32_t perTile = c->geom.tileSize * c->geom.tileSize;
+  FrameGeom g = c->geom; // + this batch's pixel range and slot layout (see sampleOf)
   g.batchSamples = count;
-  g.batchMagic = count > 1 ? (uint32_t)(((1ull << 32) + count - 1) / count) : 0u;
+  g.batchPixelBase = tileBegin * perTile;
+  g.batchPixels = tileCount * perTile;
+  g.batchMagic = count > 1 ? (~0ull / count) + 1ull : 0ull; // ceil(2^64 / count) for count >= 2
+  {
+    uint32_t lg = 6;
+    for (uint32_t sN = count; sN > 1 && lg > 0; sN >>= 1)
+      lg--;
+    if (c->groupLg >= 0)
+      lg = (uint32_t)std::min(c->groupLg, 6);
+    g.batchLg = lg;
+  }
+  const uint32_t numSlots = g.batchPixels * count;
   const uint32_t shadeBlocks = std::max(1u, std::min((numSlots + kShadeRun * kWavesPerBlock - 1) / (kShadeRun * kWavesPerBlock), (uint32_t)c->numCUs * 8u));
   HIPCHK(hipStreamWaitEvent(c->stream, c->evFrame, 0)); // the frame prologue (k_camera) may have run on the other slot's stream
   HIPCHK(hipMemsetAsync(c->fetch.p, 0, c->fetch.n * sizeof(uint32_t), c->stream)); // batch counters + work-fetch counters
@@ -500,8 +513,7 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, hipEvent_t acc
     HIPCHK(hipStreamWaitEvent(c->stream, accumulateAfter, 0));
   {
     KernelTimer kt(c, 4);
-    hipLaunchKernelGGL(k_accumulate, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, g, pathBuffers(c), c->acc.p, count, c->accFresh ? 1u : 0u);
-    c->accFresh = false;
+    hipLaunchKernelGGL(k_accumulate, dim3((g.batchPixels + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, g, pathBuffers(c), c->acc.p, count, fresh ? 1u : 0u);
     HIPCHK(hipGetLastError());
   }
   hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, c->stream, batchCounters(c), frameTotals(c));
@@ -513,6 +525,32 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, hipEvent_t acc
   return 0;
 }
 
+// How a render call's passes are cut into launch batches.  A batch is (a range of the local tiles) x (a range of the
+// call's sample passes): all samples of a pixel that the call renders stay together as long as one tile's worth of them
+// fits the path cap -- that is what makes a wave's rays coherent (see sampleOf) -- and the image is cut by tiles.
+struct BatchPlan
+{
+  uint32_t samples; // sample passes per batch
+  uint32_t tiles;   // tiles per batch
+};
+BatchPlan planBatches(const rthip_ctx* c, uint32_t count, const FrameGeom& g, uint32_t aovDepths, bool pipelined)
+{
+  BatchPlan bp;
+  if (aovDepths)
+  {
+    bp.samples = std::min(count, 4u); // AOV arrays are [sample][depth][pixel of the frame]
+    bp.tiles = g.numLocalTiles;
+    return bp;
+  }
+  const uint64_t perTile = (uint64_t)g.tileSize * g.tileSize;
+  bp.samples = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(count, c->pathCap / perTile));
+  bp.tiles = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g.numLocalTiles, c->pathCap / (perTile * bp.samples)));
+  // a call that fits one batch but is big enough to fill the GPU twice over is cut in two, one half per slot
+  if (pipelined && bp.tiles == g.numLocalTiles && bp.samples == count && g.numLocalTiles >= 2 && perTile * g.numLocalTiles * count >= (1ull << 23))
+    bp.tiles = (g.numLocalTiles + 1) / 2;
+  return bp;
+}
+
 int renderPasses(rthip_ctx* c, uint32_t sampBegin, uint32_t count, bool sync)
 {
   if (!c->haveScene || !c->haveFrame)
@@ -522,42 +560,37 @@ int renderPasses(rthip_ctx* c, uint32_t sampBegin, uint32_t count, bool sync)
   HIPCHK(hipSetDevice(c->device));
   // Two batches in flight (see rthip_ctx::Slot): no batch needs a host round trip, so batches alternate between two sets of
   // path buffers and streams -- across calls and frames too -- and the ramp and tail of one batch's launches are filled by
-  // the other's.  A call with several passes is split in two pieces (more pieces measured slower in round 1).  Nothing
-  // joins the slots at the end of the call; only the accumulate kernels are chained (per-pixel sums stay in sample order).
-  const bool pipelined = c->pipelineBatches && c->aovDepths == 0;
-  uint32_t piece = c->batchCap;
-  if (pipelined)
+  // the other's.  Nothing joins the slots at the end of the call; only the accumulate kernels are chained (per-pixel sums
+  // stay in sample order).
+  const bool pipelined = c->framePipelined;
+  const BatchPlan bp = planBatches(c, count, c->geom, c->aovDepths, pipelined);
+  const bool fresh = c->accFresh; // first call of the frame: its batches cover every local pixel once per sample range
+  for (uint32_t done = 0; done < count; done += bp.samples)
   {
-    if (count >= 2)
-      piece = std::min(c->batchCap, (count + 1) / 2);
-    swapSlot(c);
-    int rc = ensurePathBuffers(c, (size_t)c->geom.numLocalPixels * std::min(piece, count));
-    swapSlot(c);
-    if (rc)
-      return rc;
-  }
-  uint32_t done = 0;
-  while (done < count)
-  {
-    const uint32_t n = std::min(piece, count - done);
-    const bool useAlt = pipelined && (c->batchToggle++ & 1u);
-    if (useAlt)
-      swapSlot(c);
-    hipEvent_t after = (c->lastAcc && c->lastAccStream != c->stream) ? c->lastAcc : nullptr;
-    int rc = renderBatch(c, sampBegin + done, n, after);
-    if (!rc)
-      rc = (int)hipEventRecord(c->evDone, c->stream);
-    c->lastAcc = c->evDone;
-    c->lastAccStream = c->stream;
-    if (useAlt)
+    const uint32_t n = std::min(bp.samples, count - done);
+    for (uint32_t t0 = 0; t0 < c->geom.numLocalTiles; t0 += bp.tiles)
     {
-      c->altPending = true;
-      swapSlot(c);
+      const uint32_t nt = std::min(bp.tiles, c->geom.numLocalTiles - t0);
+      const bool useAlt = pipelined && (c->batchToggle++ & 1u);
+      if (useAlt)
+        swapSlot(c);
+      hipEvent_t after = (c->lastAcc && c->lastAccStream != c->stream) ? c->lastAcc : nullptr;
+      int rc = renderBatch(c, sampBegin + done, n, t0, nt, fresh && done == 0, after);
+      if (!rc)
+        rc = (int)hipEventRecord(c->evDone, c->stream);
+      c->lastAcc = c->evDone;
+      c->lastAccStream = c->stream;
+      if (useAlt)
+      {
+        c->altPending = true;
+        swapSlot(c);
+      }
+      if (rc)
+        return rc;
+      // (a later batch on the same slot reuses its path buffers: same stream, so it runs after this one)
     }
-    if (rc)
-      return rc;
-    done += n; // (a later batch on the same slot reuses its path buffers: same stream, so it runs after this one)
   }
+  c->accFresh = false;
   if (sync)
   {
     if (int rc = joinSlots(c))
@@ -605,6 +638,14 @@ static int createContext(rthip_ctx* c, int device)
     if (n >= 6)
       c->pipelineBatches = std::min(pl, 16u);
   }
+  if (const char* t = getenv("RTHIP_PATHCAP_LOG2")) // tuning experiments only
+  {
+    const int v = atoi(t);
+    if (v >= 16 && v <= 30)
+      c->pathCap = 1ull << v;
+  }
+  if (const char* t = getenv("RTHIP_GROUP_LG"))
+    c->groupLg = atoi(t);
   c->traceBlocks = (uint32_t)c->numCUs * c->tuneBlocks; // 6 blocks x 4 waves = 24 waves per CU: what 24 KB of LDS per block admits
   // the static scratch of rthip_trace_rays_static: resolved once per device, with that device current
   if (device < kMaxDevices && !g_scratchPtr[device])
@@ -817,15 +858,13 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
     return RTHIP_E_LIMIT;
   g.numLocalPixels = (uint32_t)P64;
   const uint32_t aovDepths = std::min(f->aovDepths, f->maxDepth);
-  // sample passes per launch batch: as many as fit in 2^25 paths (about 100 B of state each)
-  const uint64_t pathCap = 1ull << 25;
-  uint32_t batchCap = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(f->numSamples, pathCap / P64));
-  if (aovDepths)
-    batchCap = std::min(batchCap, 4u);
-  // sampleOf's multiply-high division is exact while (slots / 16) * batch < 2^32
-  while (batchCap > 1 && (P64 * batchCap / 16) * batchCap >= (1ull << 32))
-    batchCap--;
-  const size_t numSlots = (size_t)P64 * batchCap;
+  // the largest batch any render call of this frame can make (planBatches): both slots get buffers for it
+  const bool pipelinedFrame = c->pipelineBatches && aovDepths == 0;
+  const BatchPlan widest = planBatches(c, f->numSamples, g, aovDepths, pipelinedFrame);
+  const uint64_t numSlots64 = (uint64_t)widest.tiles * ts * ts * widest.samples;
+  if (numSlots64 > (1ull << 30))
+    return RTHIP_E_LIMIT;
+  const size_t numSlots = (size_t)numSlots64;
   int rc;
   // the previous frame may still be running on either slot: its kernels read the tile table and, when a buffer has to grow,
   // the memory about to be freed
@@ -837,15 +876,23 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
     c->altPending = false;
     return 0;
   };
-  const bool grows = numSlots > c->rayO.n || P64 * 3 > c->acc.n || g.numLocalTiles > c->tileIds.n || !c->camConsts.p || !c->totals.p ||
-                     (aovDepths && numSlots * aovDepths > c->aovTri.n);
+  const bool grows = numSlots > c->rayO.n || (pipelinedFrame && numSlots > c->alt.rayO.n) || P64 * 3 > c->acc.n || g.numLocalTiles > c->tileIds.n || !c->camConsts.p || !c->totals.p ||
+                     (aovDepths && (size_t)P64 * widest.samples * aovDepths > c->aovTri.n);
   if (grows && (rc = quiesce()))
     return rc;
   if ((rc = c->tileIds.ensure(g.numLocalTiles)) || (rc = ensurePathBuffers(c, numSlots)) || (rc = c->acc.ensure(P64 * 3)) ||
       (rc = c->img.ensure(P64 * 3)) || (rc = c->camConsts.ensure(2)) || (rc = c->totals.ensure(2)))
     return rc;
-  if (aovDepths && ((rc = c->aovTri.ensure(numSlots * aovDepths)) || (rc = c->aovShadow.ensure(numSlots * aovDepths))))
+  if (aovDepths && ((rc = c->aovTri.ensure((size_t)P64 * widest.samples * aovDepths)) || (rc = c->aovShadow.ensure((size_t)P64 * widest.samples * aovDepths))))
     return rc;
+  if (pipelinedFrame)
+  {
+    swapSlot(c);
+    rc = ensurePathBuffers(c, numSlots);
+    swapSlot(c);
+    if (rc)
+      return rc;
+  }
   {
     std::vector<uint32_t> xy(g.numLocalTiles);
     for (uint32_t k = 0; k < g.numLocalTiles; ++k)
@@ -868,7 +915,7 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
   c->camera = *camera;
   c->maxDepth = f->maxDepth;
   c->aovDepths = aovDepths;
-  c->batchCap = batchCap;
+  c->framePipelined = pipelinedFrame;
   c->accFresh = true; // CPURenderer.cpp:142-143: the clear is folded into the first k_accumulate (or done on a read before it)
   // Camera constants and counter totals are double-buffered per frame: at most two frames are in flight (one per slot; a
   // third queues behind the first on that slot's stream).  The prologue kernel goes to the stream the frame's first batch
@@ -876,7 +923,7 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
   // waits for evFrame.  A frame that never rendered keeps its parity (its buffers are nobody else's).
   if (c->renderedAny || !c->haveFrame)
     c->frameParity ^= 1u;
-  const bool firstOnAlt = c->pipelineBatches && aovDepths == 0 && (c->batchToggle & 1u);
+  const bool firstOnAlt = pipelinedFrame && (c->batchToggle & 1u);
   hipStream_t prologue = firstOnAlt ? c->alt.stream : c->stream;
   hipLaunchKernelGGL(k_camera, dim3(1), dim3(64), 0, prologue, *camera, frameCamera(c), frameTotals(c));
   HIPCHK(hipGetLastError());
