@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- the headline benchmark: Mrays/s (primary + secondary) of the MI355X backend.
 
-A "step" is one whole frame of the workload: frame prologue (clear) + every sample pass through
-generate / extend / shade / shadow / accumulate, and at N > 1 the RCCL gather of the accumulator to rank 0.
-At N = 1 the workload is BASELINE.json configs[1]: the reference's own scene (unit cube == res/models/cube.fbx,
-lights and camera of src/main.cpp:9-24) at 1920x1080, 16 spp, primary + shadow rays (depth cap 1).
-At N > 1 the image grows with N (N x the pixels, same camera) and its 64x64 tiles are dealt round-robin to the
-ranks, so per-GPU work is fixed: weak scaling.  value = rays cast by all ranks / wall time of the K timed steps.
+A "step" is one whole frame of the workload: frame prologue + every sample pass through generate / extend / shade /
+shadow / accumulate, and at N > 1 the gather of the accumulator to rank 0.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cube|bunny|soup1m|hf10m]
+Workload (every N): BASELINE.json configs[3] -- the 9,999,392-triangle height field (seed 0x5EED0002, full replica per
+GPU), 3840x2160, 64 spp, full paths (depth cap 12, two directional lights).  At N = 1 one GPU renders the whole frame; at
+N > 1 the SAME frame is split by 64x64 tiles dealt round-robin to the ranks and gathered over RCCL: total work is fixed,
+so the scaling is "strong".  value = rays cast by all ranks per frame / wall time per frame.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hf10m|soup1m|cube|bunny|hf8k|...]
 """
 import argparse
 import json
@@ -21,40 +22,135 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md "Chip-level parameters")
-CPU_WORKERS = 14       # the box gives 16 host cores per GPU; the reference uses hardware_concurrency()-2 (ThreadPool.h:29)
+# peaks (MI355X_MICROARCH.md "Chip-level parameters"; VALU: one wave64 instruction per 2 cycles per SIMD, measured by
+# tools/ubench/valu_rate -> profiles/r02_valu_rate.txt: 1.06 ns per fma wave-instruction per SIMD)
+HBM_PEAK_GBS = 8000.0
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # 1228.8 G wave64 VALU instructions per second
 
 
-def weak_resolution(base_w, base_h, n):
-    """N x the pixels of the base frame: 1 -> 1920x1080, 2 -> 1920x2160, 4 -> 3840x2160, 8 -> 3840x4320."""
-    w, h, k = base_w, base_h, n
-    grow_h = True
-    while k > 1:
-        if grow_h:
-            h *= 2
-        else:
-            w *= 2
-        grow_h = not grow_h
-        k //= 2
-    return w, h
+def cpu_workers():
+    """The reference's worker count, hardware_concurrency() - 2 (ThreadPool.h:29), on the cores this job may use: the GPU
+    box hands a one-GPU job 16 of the machine's cores."""
+    cores = min(os.cpu_count() or 16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 16, 16)
+    return max(1, cores - 2), cores
 
 
 def workloads():
     from raytracer_amd import scenes
     return {
+        "hf10m": dict(spec=scenes.hf10m_scene, width=3840, height=2160, spp=64, max_depth=12, flat_cpu=True,
+                      name="height field 2236^2 quads = 9,999,392 tris seed 0x5EED0002, 3840x2160 64spp full paths (depth cap 12) [BASELINE configs[3]]"),
+        "hf10m4": dict(spec=scenes.hf10m_scene, width=3840, height=2160, spp=4, max_depth=12, flat_cpu=True,
+                       name="height field 2236^2 quads = 9,999,392 tris seed 0x5EED0002, 3840x2160 4spp full paths (quick variant of configs[3])"),
+        "hf8k": dict(spec=scenes.hf10m_scene, width=7680, height=4320, spp=256, max_depth=12, flat_cpu=True,
+                     name="height field 9,999,392 tris, 7680x4320 256spp full paths (depth cap 12) [BASELINE configs[4]]"),
+        "soup1m": dict(spec=scenes.soup1m_scene, width=1920, height=1080, spp=1, max_depth=4, flat_cpu=True,
+                       name="triangle soup 2^20 tris seed 0x5EED0001, 1920x1080 1spp primary+3 bounces [BASELINE configs[2]]"),
         "cube": dict(spec=scenes.cube_scene, width=1920, height=1080, spp=16, max_depth=1, flat_cpu=False,
                      name="cube (== res/models/cube.fbx, main.cpp scene) 1920x1080 16spp primary+shadow [BASELINE configs[1]]"),
         "cube12": dict(spec=scenes.cube_scene, width=1920, height=1080, spp=16, max_depth=12, flat_cpu=False,
                        name="cube 1920x1080 16spp full paths (depth cap 12)"),
         "bunny": dict(spec=scenes.bunny_scene, width=1920, height=1080, spp=16, max_depth=1, flat_cpu=True,
                       name="stanford-bunny.obj (69,451 tris) 1920x1080 16spp primary+shadow"),
-        "soup1m": dict(spec=lambda: scenes.soup_scene(1 << 20, 0x5EED0001, 0.02), width=1920, height=1080, spp=1, max_depth=4, flat_cpu=True,
-                       name="triangle soup 2^20 tris seed 0x5EED0001, 1920x1080 1spp primary+3 bounces [BASELINE configs[2]]"),
-        "hf10m": dict(spec=lambda: scenes.heightfield_scene(2236, 0x5EED0002), width=3840, height=2160, spp=64, max_depth=12, flat_cpu=True,
-                      name="height field 2236^2 quads = 9,999,392 tris seed 0x5EED0002, 3840x2160 64spp full paths [BASELINE configs[3]]"),
-        "hf10m4": dict(spec=lambda: scenes.heightfield_scene(2236, 0x5EED0002), width=3840, height=2160, spp=4, max_depth=12, flat_cpu=True,
-                       name="height field 2236^2 quads = 9,999,392 tris seed 0x5EED0002, 3840x2160 4spp full paths (quick variant of configs[3])"),
     }
+
+
+KERNEL_NAMES = {"extend": "k_trace<PRIMARY|CLOSEST> (extend)", "shadow": "k_trace<SHADOW>", "generate": "k_generate", "shade": "k_shade",
+                "accumulate": "k_accumulate"}
+
+
+def roofline_block(workload, ktimes, wc, spp):
+    """roofline of the dominant kernel family.  `achieved` is ALGORITHMIC bytes per launch / average launch duration
+    (per ray 32 B ray record + 16 B hit record (any-hit: 4) + 64 B per node and per triangle record visited,
+    counted by the device).  Next to it: the HBM bytes the counters saw (profiles/traffic.json, from rocprofv3 --pmc passes
+    of this same command, FETCH_SIZE x2 + WRITE_SIZE) and the VALU issue rate, each against its own peak; `bound` names the
+    ceiling the kernel is closest to, by that evidence (None when no counter data exists for the workload)."""
+    n_ext = wc["extendPrimary"] + wc["extendSecondary"]
+    n_paths = wc["extendPrimary"]
+    alg_bytes = {
+        # fused primary rays are never stored: they carry a hit record only
+        "extend": 16.0 * wc["extendPrimary"] + 48.0 * wc["extendSecondary"] + 64.0 * (wc["nodesVisitedExtend"] + wc["trisTestedExtend"]),
+        "shadow": 36.0 * wc["shadow"] + 64.0 * ((wc["nodesVisited"] - wc["nodesVisitedExtend"]) + (wc["trisTested"] - wc["trisTestedExtend"])),
+        "generate": 32.0 * n_paths,
+        "shade": (32.0 + 16.0 + 32.0) * n_ext,                # ray + hit read, next ray written, per shaded ray
+        "accumulate": 24.0 * n_paths / spp + 17.0 * n_paths,  # accumulator read+write per pixel + radiance and liveness byte per sample
+    }
+    ktimes = {k: v for k, v in ktimes.items() if k in alg_bytes}
+    dominant = max(ktimes, key=lambda k: ktimes[k][0])
+    k_ms, k_launches = ktimes[dominant]
+    k_s = max(k_ms * 1e-3, 1e-12)
+    achieved = alg_bytes[dominant] / k_s / 1e9
+    counters = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            counters = json.load(open(tpath)).get(workload, {}).get(dominant, {}) or {}
+        except Exception:
+            counters = {}
+    if not isinstance(counters, dict):
+        counters = {}
+    traffic = counters.get("hbm_bytes_per_launch")
+    valu_insts = counters.get("valu_insts_per_launch")
+    launch_s = k_s / max(1e-9, k_launches)
+    hbm_frac = (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None
+    valu_frac = (valu_insts / launch_s / 1e9 / VALU_PEAK_GINST) if valu_insts else None
+    bound = None
+    if hbm_frac is not None and valu_frac is not None:
+        bound = "hbm" if hbm_frac >= valu_frac else "valu"
+    return {"bound": bound, "kernel": KERNEL_NAMES[dominant], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "hbm_counters": {"bytes_per_launch": traffic, "GB/s": round(traffic / launch_s / 1e9, 1) if traffic else None,
+                             "frac_of_hbm_peak": round(hbm_frac, 4) if hbm_frac is not None else None,
+                             "l2_hit_rate": counters.get("l2_hit_rate")},
+            "valu": {"wave_insts_per_launch": valu_insts, "Ginst/s": round(valu_insts / launch_s / 1e9, 1) if valu_insts else None,
+                     "peak_Ginst/s": VALU_PEAK_GINST, "frac_of_valu_peak": round(valu_frac, 4) if valu_frac is not None else None,
+                     "lane_utilisation": counters.get("valu_lane_utilisation")},
+            "algorithmic_bytes_per_launch": round(alg_bytes[dominant] / max(1e-9, k_launches), 1),
+            "avg_launch_ms": round(k_ms / max(1e-9, k_launches), 5), "launches_per_step": round(k_launches, 2),
+            "nodes_per_extend_ray": round(wc["nodesVisitedExtend"] / max(1, n_ext), 3),
+            "tris_per_extend_ray": round(wc["trisTestedExtend"] / max(1, n_ext), 3),
+            "kernel_ms_per_step": {k: round(v[0], 4) for k, v in ktimes.items()},
+            "note": "kernel durations are HIP-event pairs around every launch while batches overlap on two stream sets, as in the timed steps"}
+
+
+def cpu_baseline(spec, wl, flat, seconds):
+    """The oracle (restated src/cpu ThreadPool path) on this box's host cores, on a bounded sample of the same workload."""
+    from tests import scenes as oracle_side  # the checker / baseline (imports oracle/), never the thing measured above
+    workers, cores = cpu_workers()
+    spec.__class__ = oracle_side.SceneSpec
+    oracle = spec.build_oracle()
+    bw, bh, spp, max_depth = wl["width"], wl["height"], wl["spp"], wl["max_depth"]
+    if wl["flat_cpu"]:
+        oracle.set_flat(flat["model_nodes"], flat["nodes"], flat["tris"], flat["info_bytes"])
+    ocam = spec.oracle_camera()
+    # calibrate on a 1/16 window, then size the sample to the time budget
+    win = (bw // 2 - bw // 8, bh // 2 - bh // 8, bw // 2 + bw // 8, bh // 2 + bh // 8)
+    t1 = time.perf_counter()
+    res = oracle.render(ocam, bw, bh, spp, max_depth=max_depth, window=win, samples=(0, 1), workers=workers, flat=wl["flat_cpu"])
+    cal = time.perf_counter() - t1
+    full_pass_est = cal * 16.0
+    if full_pass_est <= seconds:
+        passes = int(max(1, min(spp, seconds // max(full_pass_est, 1e-3))))
+        reps = int(max(1, min(64, seconds // max(full_pass_est * passes, 1e-3))))
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            res = oracle.render(ocam, bw, bh, spp, max_depth=max_depth, samples=(0, passes), workers=workers, flat=wl["flat_cpu"])
+        cpu_s = (time.perf_counter() - t1) / reps
+        sample = f"{passes} of {spp} sample passes of the full {bw}x{bh} frame, timed {reps}x"
+    else:
+        reps = int(max(1, min(16, seconds // max(cal, 1e-3))))
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            res = oracle.render(ocam, bw, bh, spp, max_depth=max_depth, window=win, samples=(0, 1), workers=workers, flat=wl["flat_cpu"])
+        cpu_s = (time.perf_counter() - t1) / reps
+        sample = f"1 sample pass of the centre {win[2] - win[0]}x{win[3] - win[1]} window of the {bw}x{bh} frame, timed {reps}x"
+    oc = res["counters"]
+    cpu_rays = oc["extendPrimary"] + oc["extendSecondary"] + oc["shadow"]
+    return {"value": round(cpu_rays / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": workers, "host_cores_available": cores, "kind": "port",
+            "sample": sample + (" (variant B: CPU walk of the same flattened BVH)" if wl["flat_cpu"] else
+                                " (variant A: reference-faithful model tree + linear triangle scan)") +
+            f", ThreadPool restatement with {workers} workers (hardware_concurrency()-2 of the {cores} cores this job may use), g++ -O2 -ffp-contract=off",
+            "seconds": round(cpu_s, 3)}
 
 
 def main():
@@ -62,12 +158,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cube")
+    ap.add_argument("--workload", default="hf10m")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dynamic", action="store_true", help="N>1: tiles from a shared cursor (dynamic rebalancing) instead of static round-robin")
     ap.add_argument("--tile-batch", type=int, default=16, help="--dynamic: tiles taken from the cursor at a time")
     ap.add_argument("--no-roofline", action="store_true", help="skip the extra instrumented frames (used under rocprofv3 --pmc)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the bounded CPU-baseline sample")
+    ap.add_argument("--torch-gather", action="store_true", help="N>1: gather with torch.distributed instead of rthip_gather (the C ABI's RCCL gather)")
     args = ap.parse_args()
 
     import torch
@@ -92,12 +189,10 @@ def main():
         else:
             dist.init_process_group(backend)
     n_gpus = max(args.gpus, world) if world > 1 else 1
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
 
     wl = workloads()[args.workload]
     spec = wl["spec"]()
-    width, height = weak_resolution(wl["width"], wl["height"], world)
+    width, height = wl["width"], wl["height"]  # the same frame at every N: strong scaling
     spp, max_depth, ts = wl["spp"], wl["max_depth"], 64
 
     r = spec.build_product(options=dict(maxDepth=max_depth), device=local_rank)
@@ -108,53 +203,69 @@ def main():
     cam = spec.product_camera()
     hl = ra.capi.hip_lib()
     ctx = r.context
+    dev = f"cuda:{local_rank}"
     n_local_floats = len(assignment[rank]) * ts * ts * 3 if world > 1 else None
-    local_buf = None
-    full_frame = torch.zeros((height, width, 3), dtype=torch.float32, device=f"cuda:{local_rank}") if (world > 1 and rank == 0) else None
+    full_frame = torch.zeros((height, width, 3), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
     gather_ms = []
-
     tiles_total = int(sum(len(a) for a in assignment))
     dynamic = args.dynamic and world > 1
+    # the C ABI's own RCCL gather (rthip_gather) unless rehearsing over gloo or asked otherwise
+    native_gather = world > 1 and backend == "nccl" and not args.torch_gather and not dynamic
+    per_rank_floats = rdist.padded_tile_count(assignment) * ts * ts * 3
+    gathered = None
+    if native_gather:
+        rdist.init_native_comm(r, dist, rank, world)
+        if rank == 0:
+            gathered = torch.empty((world, per_rank_floats), dtype=torch.float32, device=dev)
+
     queue = None
+    local_buf = None
     if dynamic:
         queue = rdist.TileQueue(rdist.make_queue_store(dist, rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1")), tiles_total, args.tile_batch)
-        # a rank may end up with any number of tiles: room for all of them
-        local_buf = torch.empty((tiles_total * ts * ts, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
+        local_buf = torch.empty((tiles_total * ts * ts, 3), dtype=torch.float32, device=dev)  # a rank may end up with any number of tiles
     frame_no = [0]
     tile_counts, finish_times = [], []
-
     step_rays = np.zeros(4)  # dynamic mode: rays of the current step, summed over its tile batches
 
     stage = recv = None
     pending = []
-    if world > 1 and not dynamic:
-        per_rank = rdist.padded_tile_count(assignment) * ts * ts
-        stage = [torch.zeros((per_rank, 3), dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(2)]
+    if world > 1 and not dynamic and not native_gather:
+        stage = [torch.zeros((per_rank_floats // 3, 3), dtype=torch.float32, device=dev) for _ in range(2)]
         if rank == 0 and backend == "nccl":
             recv = [[torch.empty_like(stage[0]) for _ in range(world)] for _ in range(2)]
 
+    def untile_all(bufs):
+        for buf, tiles in zip(bufs, assignment):
+            rc = hl.rthip_untile(ctx, buf.data_ptr(), ra.capi._up(tiles), len(tiles), full_frame.data_ptr())
+            assert rc == 0, ra.capi.error_string(rc)
+
     def drain():
-        """Completes the gather in flight (if any); rank 0 scatters the tiles it brought into the row-major frame."""
+        """Completes the torch gather in flight (if any); rank 0 scatters the tiles it brought into the row-major frame."""
         while pending:
             work, dst, _src = pending.pop(0)
             work.wait()
             if backend == "nccl":
                 torch.cuda.current_stream().synchronize()
             if rank == 0:
-                for buf, tiles in zip(dst, assignment):
-                    buf = buf if backend == "nccl" else buf.to(f"cuda:{local_rank}")
-                    rc = hl.rthip_untile(ctx, buf.data_ptr(), ra.capi._up(tiles), len(tiles), full_frame.data_ptr())
-                    assert rc == 0, ra.capi.error_string(rc)
+                untile_all([b if backend == "nccl" else b.to(dev) for b in dst])
 
     def step():
         if not dynamic:
-            # frames are queued back to back on the context's stream (no host round trip inside a frame or between
-            # frames); the timed region ends with a synchronisation, and a multi-GPU step waits below when it copies
+            # frames are queued back to back on the context's streams (no host round trip inside a frame or between
+            # frames); the timed region ends with a synchronisation, and a multi-GPU step waits below when it gathers
             r.begin_frame(cam, width, height, spp)
             r.enqueue_passes(0, spp)
-        if world > 1 and not dynamic:
-            # The gather of frame k travels while frame k+1 renders: the accumulator is copied into one of two staging
-            # buffers, the collective is started asynchronously, and rank 0 re-tiles a frame one step later (or in drain()).
+        if native_gather:
+            # rthip_gather: the rank's tile-major accumulator goes to rank 0 over RCCL (grouped send/recv), queued on the
+            # context's stream behind the frame; rank 0 then re-tiles the gathered buffers into the row-major frame
+            t0 = time.perf_counter()
+            rc = hl.rthip_gather(ctx, gathered.data_ptr() if rank == 0 else None, per_rank_floats, 0)
+            assert rc == 0, ra.capi.error_string(rc)
+            if rank == 0:
+                untile_all([gathered[k] for k in range(world)])
+            gather_ms.append((time.perf_counter() - t0) * 1e3)
+        elif world > 1 and not dynamic:
+            # torch.distributed path: the gather of frame k travels while frame k+1 renders (two staging buffers)
             t0 = time.perf_counter()
             k = frame_no[0] & 1
             frame_no[0] += 1
@@ -193,7 +304,7 @@ def main():
                 for tiles, src in got:
                     if len(tiles) == 0:
                         continue
-                    src = src.to(f"cuda:{local_rank}").contiguous()
+                    src = src.to(dev).contiguous()
                     rc = hl.rthip_untile(ctx, src.data_ptr(), ra.capi._up(tiles), len(tiles), full_frame.data_ptr())
                     assert rc == 0, ra.capi.error_string(rc)
             torch.cuda.synchronize()
@@ -221,7 +332,7 @@ def main():
         cnt = {"extendPrimary": step_rays[1], "extendSecondary": step_rays[2], "shadow": step_rays[3]}
     rays_local = cnt["extendPrimary"] + cnt["extendSecondary"] + cnt["shadow"]
     t = torch.tensor([elapsed, float(rays_local), float(cnt["extendPrimary"]), float(cnt["extendSecondary"]), float(cnt["shadow"])],
-                     dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+                     dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -257,13 +368,17 @@ def main():
         frame_check = "assembled frame bit-identical to a single-GPU render" if same else "MISMATCH against the single-GPU render"
         r.set_tiles(assignment[rank])
 
-    # ---- roofline of the dominant kernel: per-kernel HIP-event timing + algorithmic work counts, in separate untimed frames
     if args.no_roofline:
         print(json.dumps({"metric": "Mrays/s (primary+secondary)", "value": round(value, 2), "unit": "Mrays/s", "ms_per_step": round(ms_per_step, 4)}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
         return
+
+    # ---- roofline of the dominant kernel: per-kernel HIP-event timing + algorithmic work counts, in separate untimed frames.
     # Event pairs around every launch, resolved after the streams have drained: the frames below run exactly like the timed
     # ones (batches and frames overlapping), so a kernel's average duration here is what rocprofv3 reports for it.
-    T = 5
+    T = 3 if ms_per_step > 50 else 5
     r.set_option("kernelTiming", 1)
     for _ in range(T):
         r.begin_frame(cam, width, height, spp)
@@ -275,84 +390,21 @@ def main():
     r.render_passes(0, spp)
     wc = r.counters()
     r.set_option("countWork", 0)
-    n_ext = wc["extendPrimary"] + wc["extendSecondary"]
-    n_paths = wc["extendPrimary"]
-    # ALGORITHMIC bytes: per ray 32 (ray record) + 16 (hit record; any-hit: 4) + 64 per node + 64 per triangle record
-    alg_bytes = {
-        "extend": 48.0 * n_ext + 64.0 * (wc["nodesVisitedExtend"] + wc["trisTestedExtend"]),
-        "shadow": 36.0 * wc["shadow"] + 64.0 * ((wc["nodesVisited"] - wc["nodesVisitedExtend"]) + (wc["trisTested"] - wc["trisTestedExtend"])),
-        "generate": 32.0 * n_paths,                      # one ray record written per camera sample
-        "shade": (32.0 + 16.0 + 32.0) * n_ext,           # ray + hit read, next ray written, per shaded ray
-        "accumulate": 24.0 * n_paths / spp + 12.0 * n_paths,  # accumulator read+write per pixel + one radiance per sample
-        "compact": 1.0 * n_paths,
-    }
-    dominant = max(ktimes, key=lambda k: ktimes[k][0])
-    k_ms, k_launches = ktimes[dominant]
-    achieved = alg_bytes[dominant] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    # HBM bytes per launch and VALU issue utilisation come from the committed rocprofv3 PMC passes of this same command
-    # (tools/profile_pmc.sh -> profiles/traffic.json); counters cannot be read from inside the process
-    traffic = valu_util = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            traffic = tj.get(args.workload, {}).get(dominant)
-            valu_util = tj.get("_valu_issue_utilisation", {}).get(args.workload, {}).get(dominant)
-        except Exception:
-            traffic = valu_util = None
-    roofline = {"bound": "hbm", "kernel": {"extend": "k_trace<PRIMARY|CLOSEST> (extend)", "shadow": "k_trace<SHADOW>", "generate": "k_generate",
-                                           "shade": "k_shade", "accumulate": "k_accumulate", "compact": "k_compact"}[dominant],
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "valu_issue_utilisation": valu_util, "algorithmic_bytes_per_launch": round(alg_bytes[dominant] / max(1e-9, k_launches), 1),
-                "avg_launch_ms": round(k_ms / max(1e-9, k_launches), 5), "launches_per_step": round(k_launches, 2),
-                "nodes_per_extend_ray": round(wc["nodesVisitedExtend"] / max(1, n_ext), 3),
-                "tris_per_extend_ray": round(wc["trisTestedExtend"] / max(1, n_ext), 3),
-                "kernel_ms_per_step": {k: round(v[0], 4) for k, v in ktimes.items()}}
+    roofline = roofline_block(args.workload, ktimes, wc, spp)
 
-    # ---- CPU baseline: the oracle (restated src/cpu ThreadPool path) on this box's host cores, bounded sample
     cpu = None
     if not args.no_cpu_baseline:
-        from tests import scenes as oracle_side  # the checker / baseline (imports oracle/), never the thing measured above
-        spec.__class__ = oracle_side.SceneSpec
-        oracle = spec.build_oracle()
-        bw, bh = wl["width"], wl["height"]
-        if wl["flat_cpu"]:
-            oracle.set_flat(flat["model_nodes"], flat["nodes"], flat["tris"], flat["info_bytes"])
-        ocam = spec.oracle_camera()
-        # calibrate on a 1/16 window, then size the sample to the time budget
-        win = (bw // 2 - bw // 8, bh // 2 - bh // 8, bw // 2 + bw // 8, bh // 2 + bh // 8)
-        t1 = time.perf_counter()
-        res = oracle.render(ocam, bw, bh, spp, max_depth=max_depth, window=win, samples=(0, 1), workers=CPU_WORKERS, flat=wl["flat_cpu"])
-        cal = time.perf_counter() - t1
-        full_pass_est = cal * 16.0
-        if full_pass_est <= args.cpu_seconds:
-            passes = int(max(1, min(spp, args.cpu_seconds // max(full_pass_est, 1e-3))))
-            # repeat the sample until about cpu_seconds of CPU work have been timed (a sub-second sample is noisy)
-            reps = int(max(1, min(64, args.cpu_seconds // max(full_pass_est * passes, 1e-3))))
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                res = oracle.render(ocam, bw, bh, spp, max_depth=max_depth, samples=(0, passes), workers=CPU_WORKERS, flat=wl["flat_cpu"])
-            cpu_s = (time.perf_counter() - t1) / reps
-            sample = f"{passes} of {spp} sample passes of the full {bw}x{bh} frame, timed {reps}x"
-        else:
-            cpu_s = cal
-            sample = f"1 sample pass of the centre {win[2] - win[0]}x{win[3] - win[1]} window of the {bw}x{bh} frame"
-        oc = res["counters"]
-        cpu_rays = oc["extendPrimary"] + oc["extendSecondary"] + oc["shadow"]
-        cpu = {"value": round(cpu_rays / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": CPU_WORKERS, "kind": "port",
-               "sample": sample + (" (variant B: CPU walk of the same flattened BVH)" if wl["flat_cpu"] else
-                                   " (variant A: reference-faithful model tree + linear triangle scan)") +
-               f", ThreadPool restatement with {CPU_WORKERS} workers, g++ -O2 -ffp-contract=off",
-               "seconds": round(cpu_s, 3)}
+        cpu = cpu_baseline(spec, wl, flat, args.cpu_seconds)
 
     out = {"metric": "Mrays/s (primary+secondary)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": wl["name"], "width": width, "height": height, "spp": spp, "max_depth": max_depth,
-                      "tris": int(flat["info"].numTris), "bvh_nodes": int(flat["info"].numNodes),
+                      "tris": int(flat["info"].numTris), "bvh_nodes": int(flat["info"].numNodes), "bvh_build_seconds": round(float(flat["build_seconds"]), 3),
                       "rays_per_step": int(rays_frame), "primary": int(t[2]), "secondary_extend": int(t[3]), "shadow": int(t[4]),
-                      "parallelism": (f"tiles64-{'dynamic' if dynamic else 'rr'}-x{world}-{backend}" if world > 1 else "single"), "balance": balance,
-                      "gather_ms": round(float(np.mean(gather_ms)), 4) if gather_ms else None, "frame_check": frame_check},
+                      "parallelism": (f"tiles64-{'dynamic' if dynamic else 'rr'}-x{world}-{backend}-{'rthip_gather' if native_gather else 'torch_gather'}"
+                                      if world > 1 else "single"),
+                      "balance": balance, "gather_ms": round(float(np.mean(gather_ms)), 4) if gather_ms else None, "frame_check": frame_check},
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
     if world > 1:

@@ -38,13 +38,14 @@ void rt_mesh_destroy(rt_mesh*);
 /* ---- renderer: Renderer (src/scene/Renderer.h:14-42) with backend "hip" ---- */
 int rt_renderer_create(const char* backend, int device, rt_renderer** out);   /* std::make_unique<...Renderer>(), main.cpp:8 */
 void rt_renderer_destroy(rt_renderer*);
+/* lights and meshes are accepted until rt_generate (RTHIP_E_STATE afterwards: they are uploaded with the scene) */
 int rt_add_directional_light(rt_renderer*, const float direction[3], const float color[3]); /* Renderer::addDirectionalLight */
 int rt_add_point_light(rt_renderer*, const float position[3], const float color[3], float attenuation); /* ::addPointLight */
 /* Renderer::addModel(PModel, glm::mat4): the mesh is copied, transform is 16 floats column-major */
 int rt_add_mesh(rt_renderer*, const rt_mesh*, const float transform[16]);
 int rt_generate(rt_renderer*);                                                 /* Renderer::generate */
 
-/* options the reference hard-codes: name in {"maxDepth","aovDepths","tileSize","passesPerCall",
+/* options the reference hard-codes: name in {"maxDepth","aovDepths","tileSize","passesPerCall","chunkMs",
  * "referenceEdgeIndexing","maxLeafTriangles","sahBins","buildThreads","originBoundScale","countWork","kernelTiming","fusedPrimary","pipelining"};
  * scene options must be set before rt_generate */
 int rt_set_option(rt_renderer*, const char* name, double value);
@@ -52,7 +53,7 @@ int rt_set_tiles(rt_renderer*, const uint32_t* tileIds, uint32_t numTiles);    /
 
 int rt_start_render(rt_renderer*, const rthip_camera* camera, uint32_t width, uint32_t height, uint32_t numSamples); /* ::startRender */
 int rt_wait_render(rt_renderer*);     /* joins the render thread; returns the render's error code */
-int rt_cancel_render(rt_renderer*);   /* running = false + join (Renderer.cpp:13-17) */
+int rt_cancel_render(rt_renderer*);   /* running = false + join (Renderer.cpp:13-17); returns within about one chunk ("chunkMs", 50 ms) of device work */
 /* synchronous stepping for hosts that run the `samp` loop themselves (src/cpu/CPURenderer.cpp:144): rt_begin_frame
  * is render()'s prologue (:140-143), rt_render_passes runs passes [begin, begin+count) on the calling thread and
  * reports the device time of the call */
@@ -78,6 +79,10 @@ int rt_get_flat(rt_renderer*, const rtflat_info** info, const rtflat_model_node*
                 const rtflat_tri** tris, double* buildSeconds);
 /* the low-level context, for device-pointer level integration (multi-GPU gather) and probes */
 rthip_ctx* rt_context(rt_renderer*);
+/* multi-GPU assembly, one renderer per GPU / process (forwards to rthip_comm_init / rthip_gather; the id comes from
+ * rthip_comm_unique_id on one rank) */
+int rt_comm_init(rt_renderer*, const unsigned char id[RTHIP_COMM_ID_BYTES], int rank, int worldSize);
+int rt_gather(rt_renderer*, float* recvDev, uint64_t floatsPerRank, int root);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,7 @@ extern "C" {
 #define RTHIP_E_BOUNDS (-3)    /* camera outside rtflat_info.originBound: box padding would not be conservative */
 #define RTHIP_E_NODEVICE (-4)  /* no usable HIP device */
 #define RTHIP_E_LIMIT (-5)     /* size beyond a compiled-in maximum */
+#define RTHIP_E_COMM (-6)      /* RCCL could not be loaded or returned an error (rthip_error_string has its text) */
 
 typedef struct rthip_ctx rthip_ctx;
 
@@ -54,7 +55,7 @@ typedef struct rthip_frame_desc
   uint32_t width, height, numSamples; /* RenderParameter (src/scene/Renderer.h:7-12) */
   uint32_t maxDepth;                  /* path depth cap; the reference hard-codes 12 (src/cpu/CPUScene.cpp:15) */
   uint32_t aovDepths;                 /* record hit-id / shadow AOVs for this many depths of each pass (0 = off) */
-  uint32_t tileSize;                  /* square tile edge in pixels (multiple of 8); 0 = default 64 */
+  uint32_t tileSize;                  /* square tile edge in pixels (a power of two >= 8); 0 = default 64 */
   uint32_t numTiles;                  /* tiles this context renders; 0 = the whole image */
   uint32_t pad;
   const uint32_t* tileIds;            /* numTiles tile indices (row-major over ceil(W/ts) x ceil(H/ts)); NULL with numTiles 0 */
@@ -94,7 +95,8 @@ int rthip_begin(rthip_ctx* ctx, const rthip_camera* camera, const rthip_frame_de
  * src/cpu/CPUScene.cpp:6-65 inside).  msOut (may be NULL): device time of the whole call in ms, measured with
  * HIP events on the context's stream. Blocks until the passes are done. */
 int rthip_render_passes(rthip_ctx* ctx, uint32_t sampBegin, uint32_t count, float* msOut);
-/* same, but only enqueues on the context's stream (no host synchronisation, no timing) */
+/* same, but only enqueues on the context's streams: no host synchronisation at any depth cap (path counts stay on the
+ * device), no timing */
 int rthip_enqueue_passes(rthip_ctx* ctx, uint32_t sampBegin, uint32_t count);
 int rthip_synchronize(rthip_ctx* ctx);
 
@@ -116,6 +118,22 @@ int rthip_copy_accumulator_to(rthip_ctx* ctx, float* dstDev, uint64_t numFloats)
 /* scatters a gathered tile-major buffer (device memory, tiles listed in tileIds) into a row-major
  * width*height*3 device image */
 int rthip_untile(rthip_ctx* ctx, const float* tileMajorDev, const uint32_t* tileIds, uint32_t numTiles, float* rowMajorDev);
+
+/* Multi-GPU assembly over RCCL (one process per GPU, full scene replica per rank, image tiles as the shard).
+ * The reference has no counterpart (single process, src/main.cpp); these take the place of the per-frame GL upload
+ * (src/cpu/CPURenderer.cpp:127-136) on a multi-GPU host.  RCCL is loaded at run time (dlopen), not linked.
+ *  rthip_comm_unique_id: one rank creates the communicator id (ncclGetUniqueId) and hands the bytes to the others by any side
+ *                        channel (a file, MPI, a torch.distributed store);
+ *  rthip_comm_init:      every rank joins (ncclCommInitRank) with its context, i.e. its GPU;
+ *  rthip_gather:         every rank sends its tile-major accumulator, zero-padded to floatsPerRank floats, to `root` with grouped
+ *                        ncclSend / ncclRecv on the context's stream; on root recvDev (device memory on its GPU, worldSize *
+ *                        floatsPerRank floats) receives rank k's block at k * floatsPerRank.  Enqueue-only: rthip_untile on
+ *                        the root context (same stream) or rthip_synchronize orders itself behind it. */
+#define RTHIP_COMM_ID_BYTES 128
+int rthip_comm_unique_id(unsigned char idOut[RTHIP_COMM_ID_BYTES]);
+int rthip_comm_init(rthip_ctx* ctx, const unsigned char id[RTHIP_COMM_ID_BYTES], int rank, int worldSize);
+int rthip_comm_destroy(rthip_ctx* ctx);
+int rthip_gather(rthip_ctx* ctx, float* recvDev, uint64_t floatsPerRank, int root);
 
 int rthip_get_counters(rthip_ctx* ctx, rthip_counters* out); /* totals since rthip_begin */
 /* 1: count nodesVisited/trisTested in the traversal kernels (slower); 0: off (default) */

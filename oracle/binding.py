@@ -192,8 +192,9 @@ class OracleScene:
         tri = shadow = None
         tp = sp = None
         if aov_depths:
-            tri = np.zeros((num_samples, aov_depths, height, width), np.uint32)
-            shadow = np.zeros((num_samples, aov_depths, height, width), np.uint8)
+            # planes [0, s1): the oracle only touches those of the passes it renders
+            tri = np.zeros((s1, aov_depths, height, width), np.uint32)
+            shadow = np.zeros((s1, aov_depths, height, width), np.uint8)
             tp = tri.ctypes.data_as(C.POINTER(C.c_uint32))
             sp = shadow.ctypes.data_as(C.POINTER(C.c_uint8))
         times = np.zeros(num_samples, np.float32)

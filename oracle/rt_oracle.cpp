@@ -869,10 +869,12 @@ int orc_render(orc_scene* s, const orc_camera* cam, const orc_render_params* prm
     std::memset(accumulator, 0, plane * 3 * sizeof(float));
     std::memset(image, 0, plane * 3 * sizeof(float));
   }
-  if (prm->aovDepths && aovTriId && prm->sampBegin == 0)
+  if (prm->aovDepths && aovTriId)
   {
-    std::memset(aovTriId, 0xff, (size_t)prm->numSamples * prm->aovDepths * plane * sizeof(uint32_t));
-    std::memset(aovShadow, 0xff, (size_t)prm->numSamples * prm->aovDepths * plane);
+    // only the planes of the passes this call renders (the caller's arrays need not reach past sampEnd)
+    const size_t first = (size_t)prm->sampBegin * prm->aovDepths * plane, count = (size_t)(prm->sampEnd - prm->sampBegin) * prm->aovDepths * plane;
+    std::memset(aovTriId + first, 0xff, count * sizeof(uint32_t));
+    std::memset(aovShadow + first, 0xff, count);
   }
   if (counters && prm->sampBegin == 0)
     std::memset(counters, 0, sizeof(*counters));

@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_HOST = os.path.join(_HERE, "libraytracer_amd.so")
 LIB_HIP = os.path.join(_HERE, "librthip.so")
 
-RTHIP_E_ARG, RTHIP_E_STATE, RTHIP_E_BOUNDS, RTHIP_E_NODEVICE, RTHIP_E_LIMIT = -1, -2, -3, -4, -5
+RTHIP_E_ARG, RTHIP_E_STATE, RTHIP_E_BOUNDS, RTHIP_E_NODEVICE, RTHIP_E_LIMIT, RTHIP_E_COMM = -1, -2, -3, -4, -5, -6
+RTHIP_COMM_ID_BYTES = 128
 RTHIP_STATIC_MAX_RAYS = 16384  # include/rthip.h
 
 
@@ -86,6 +87,10 @@ def hip_lib():
         L.rthip_probe_bounce.argtypes = [vp, fp, fp, C.c_uint32, fp]
         L.rthip_probe_trace.argtypes = [vp, fp, fp, C.c_uint32, C.c_float, C.c_float, up, fp, C.POINTER(C.c_uint8)]
         L.rthip_trace_rays_static.argtypes = [vp, vp, vp, C.c_uint32, C.c_float, C.c_float, vp, vp, vp]
+        L.rthip_comm_unique_id.argtypes = [C.c_char_p]
+        L.rthip_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+        L.rthip_comm_destroy.argtypes = [vp]
+        L.rthip_gather.argtypes = [vp, vp, C.c_uint64, C.c_int]
         L.rthip_accumulator_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
         L.rthip_untile.argtypes = [vp, vp, up, C.c_uint32, vp]
         L.rthip_copy_accumulator_to.argtypes = [vp, vp, C.c_uint64]
@@ -146,6 +151,8 @@ def host_lib():
         L.rt_get_kernel_times.argtypes = [vp, fp, up]
         L.rt_get_flat.argtypes = [vp, C.POINTER(C.POINTER(FlatInfo)), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_double)]
         L.rt_context.argtypes = [vp]
+        L.rt_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+        L.rt_gather.argtypes = [vp, vp, C.c_uint64, C.c_int]
         _host = L
     return _host
 

@@ -22,6 +22,8 @@
 // are parked and tested in separate wave steps.  With a depth cap of 1 two batches are in flight on two sets of buffers
 // (rthip_ctx::Slot).  DESIGN.md section 5 has the measurements behind each of these choices.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and prototypes only: the library is bound at run time (see RcclApi)
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -217,7 +219,70 @@ struct rthip_ctx
   uint32_t pipelineBatches = 2;  // 2: batches alternate between the two slots (two in flight); 0 = one slot only
   uint32_t batchToggle = 0;      // which slot the next batch goes to (alternates across calls and frames)
   bool framePipelined = false;   // decided by rthip_begin (both slots sized for the frame's batches)
+  // multi-GPU assembly (rthip_comm_init / rthip_gather)
+  ncclComm_t comm = nullptr;
+  int commRank = 0, commSize = 0;
+  DevBuf<float> gatherStage;     // this rank's accumulator padded to the common per-rank size
 };
+
+// RCCL is bound at run time with dlopen/dlsym instead of being linked: a host process that already carries a copy of RCCL
+// (PyTorch ships one) then shares that one copy, and a process that never gathers never loads it.
+namespace
+{
+struct RcclApi
+{
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+  decltype(&ncclCommInitRank) commInitRank = nullptr;
+  decltype(&ncclCommDestroy) commDestroy = nullptr;
+  decltype(&ncclGroupStart) groupStart = nullptr;
+  decltype(&ncclGroupEnd) groupEnd = nullptr;
+  decltype(&ncclSend) send = nullptr;
+  decltype(&ncclRecv) recv = nullptr;
+  decltype(&ncclGetErrorString) errorString = nullptr;
+  bool ok = false;
+};
+char g_commError[256] = "";
+RcclApi& rccl()
+{
+  static RcclApi api = [] {
+    RcclApi a;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if ((a.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL)))
+        break;
+    if (!a.handle)
+    {
+      snprintf(g_commError, sizeof(g_commError), "rthip: cannot load RCCL (%s)", dlerror());
+      return a;
+    }
+    a.getUniqueId = reinterpret_cast<decltype(a.getUniqueId)>(dlsym(a.handle, "ncclGetUniqueId"));
+    a.commInitRank = reinterpret_cast<decltype(a.commInitRank)>(dlsym(a.handle, "ncclCommInitRank"));
+    a.commDestroy = reinterpret_cast<decltype(a.commDestroy)>(dlsym(a.handle, "ncclCommDestroy"));
+    a.groupStart = reinterpret_cast<decltype(a.groupStart)>(dlsym(a.handle, "ncclGroupStart"));
+    a.groupEnd = reinterpret_cast<decltype(a.groupEnd)>(dlsym(a.handle, "ncclGroupEnd"));
+    a.send = reinterpret_cast<decltype(a.send)>(dlsym(a.handle, "ncclSend"));
+    a.recv = reinterpret_cast<decltype(a.recv)>(dlsym(a.handle, "ncclRecv"));
+    a.errorString = reinterpret_cast<decltype(a.errorString)>(dlsym(a.handle, "ncclGetErrorString"));
+    a.ok = a.getUniqueId && a.commInitRank && a.commDestroy && a.groupStart && a.groupEnd && a.send && a.recv && a.errorString;
+    if (!a.ok)
+      snprintf(g_commError, sizeof(g_commError), "rthip: the RCCL library lacks an entry point");
+    return a;
+  }();
+  return api;
+}
+int commFail(ncclResult_t r, const char* what)
+{
+  snprintf(g_commError, sizeof(g_commError), "rthip: %s: %s", what, rccl().errorString ? rccl().errorString(r) : "RCCL error");
+  return RTHIP_E_COMM;
+}
+#define NCCLCHK(x, what)             \
+  do                                 \
+  {                                  \
+    ncclResult_t r_ = (x);           \
+    if (r_ != ncclSuccess)           \
+      return commFail(r_, what);     \
+  } while (0)
+} // namespace
 
 namespace
 {
@@ -613,6 +678,7 @@ const char* rthip_error_string(int code)
   case RTHIP_E_BOUNDS: return "rthip: camera outside the origin bound the scene was flattened for";
   case RTHIP_E_NODEVICE: return "rthip: no usable HIP device";
   case RTHIP_E_LIMIT: return "rthip: size beyond a compiled-in limit";
+  case RTHIP_E_COMM: return g_commError[0] ? g_commError : "rthip: RCCL error";
   default: return code > 0 ? hipGetErrorString((hipError_t)code) : "rthip: unknown error";
   }
 }
@@ -697,6 +763,9 @@ int rthip_destroy(rthip_ctx* c)
   if (!c)
     return RTHIP_E_ARG;
   (void)hipSetDevice(c->device);
+  if (c->comm && rccl().ok)
+    (void)rccl().commDestroy(c->comm);
+  c->comm = nullptr;
   auto dropStream = [](hipStream_t& s) {
     if (s)
     {
@@ -1135,6 +1204,90 @@ int rthip_untile(rthip_ctx* c, const float* tileMajorDev, const uint32_t* tileId
   HIPCHK(hipStreamSynchronize(c->stream));
   ids.release();
   return 0;
+}
+
+// ---- multi-GPU assembly over RCCL (one gather of the fp32 accumulator at the end of a frame) ----------------
+int rthip_comm_unique_id(unsigned char idOut[RTHIP_COMM_ID_BYTES])
+{
+  static_assert(RTHIP_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the id crosses the ABI as plain bytes");
+  if (!idOut)
+    return RTHIP_E_ARG;
+  if (!rccl().ok)
+    return RTHIP_E_COMM;
+  ncclUniqueId id;
+  NCCLCHK(rccl().getUniqueId(&id), "ncclGetUniqueId");
+  std::memcpy(idOut, id.internal, RTHIP_COMM_ID_BYTES);
+  return 0;
+}
+
+int rthip_comm_init(rthip_ctx* c, const unsigned char id[RTHIP_COMM_ID_BYTES], int rank, int worldSize)
+{
+  if (!c || !id || worldSize < 1 || rank < 0 || rank >= worldSize)
+    return RTHIP_E_ARG;
+  if (c->comm)
+    return RTHIP_E_STATE;
+  if (!rccl().ok)
+    return RTHIP_E_COMM;
+  HIPCHK(hipSetDevice(c->device));
+  ncclUniqueId uid;
+  std::memcpy(uid.internal, id, RTHIP_COMM_ID_BYTES);
+  NCCLCHK(rccl().commInitRank(&c->comm, worldSize, uid, rank), "ncclCommInitRank");
+  c->commRank = rank;
+  c->commSize = worldSize;
+  return 0;
+}
+
+int rthip_comm_destroy(rthip_ctx* c)
+{
+  if (!c)
+    return RTHIP_E_ARG;
+  if (!c->comm)
+    return 0;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  NCCLCHK(rccl().commDestroy(c->comm), "ncclCommDestroy");
+  c->comm = nullptr;
+  c->commSize = 0;
+  return 0;
+}
+
+int rthip_gather(rthip_ctx* c, float* recvDev, uint64_t floatsPerRank, int root)
+{
+  if (!c || !floatsPerRank)
+    return RTHIP_E_ARG;
+  if (!c->comm || !c->haveFrame)
+    return RTHIP_E_STATE;
+  if (root < 0 || root >= c->commSize || (c->commRank == root && !recvDev))
+    return RTHIP_E_ARG;
+  const uint64_t mine = (uint64_t)c->geom.numLocalPixels * 3;
+  if (mine > floatsPerRank)
+    return RTHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  if (int rc = joinSlots(c)) // the frame's last batches may be on the second slot's stream
+    return rc;
+  if (int rc = settleAccumulator(c))
+    return rc;
+  // every rank sends the same number of floats: its tile-major accumulator, zero-padded when it owns fewer tiles
+  const float* sendBuf = c->acc.p;
+  if (mine < floatsPerRank)
+  {
+    if (int rc = c->gatherStage.ensure(floatsPerRank))
+      return rc;
+    HIPCHK(hipMemcpyAsync(c->gatherStage.p, c->acc.p, mine * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->gatherStage.p + mine, 0, (floatsPerRank - mine) * sizeof(float), c->stream));
+    sendBuf = c->gatherStage.p;
+  }
+  // grouped point-to-point: over xGMI every peer has its own link to the root, so the transfers run side by side
+  NCCLCHK(rccl().groupStart(), "ncclGroupStart");
+  ncclResult_t r = rccl().send(sendBuf, floatsPerRank, ncclFloat, root, c->comm, c->stream);
+  if (r == ncclSuccess && c->commRank == root)
+    for (int k = 0; k < c->commSize && r == ncclSuccess; ++k)
+      r = rccl().recv(recvDev + (size_t)k * floatsPerRank, floatsPerRank, ncclFloat, k, c->comm, c->stream);
+  const ncclResult_t rEnd = rccl().groupEnd();
+  if (r != ncclSuccess)
+    return commFail(r, "ncclSend/ncclRecv");
+  NCCLCHK(rEnd, "ncclGroupEnd");
+  return 0; // queued on the context's stream: rthip_untile / rthip_synchronize order themselves behind it
 }
 
 int rthip_get_counters(rthip_ctx* c, rthip_counters* out)

@@ -76,6 +76,23 @@ def gather_tiles(local, assignment, rank, world_size, dist, device=None):
     return bufs
 
 
+def init_native_comm(renderer, dist, rank, world_size):
+    """Joins the renderer's context to an RCCL communicator of its own (include/rthip.h: rthip_comm_init) so that
+    rthip_gather can assemble the frame inside the C ABI.  The communicator id travels over the existing process group."""
+    import ctypes as C
+
+    from . import capi
+    hl = capi.hip_lib()
+    box = [None]
+    if rank == 0:
+        buf = C.create_string_buffer(capi.RTHIP_COMM_ID_BYTES)
+        capi._check(hl.rthip_comm_unique_id(buf), "rthip_comm_unique_id")
+        box[0] = buf.raw
+    if world_size > 1:
+        dist.broadcast_object_list(box, src=0)
+    capi._check(hl.rthip_comm_init(renderer.context, box[0], int(rank), int(world_size)), "rthip_comm_init")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Dynamic tile ownership (SURVEY.md 8d config 5): over-decomposed tiles handed out from one shared cursor, so a GPU whose
 # tiles were cheap takes more of them instead of idling through the others' tail.  A whole tile (all its samples) is

@@ -6,6 +6,7 @@
 #include "util/ModelLoader.h"
 #include "util/Procedural.h"
 
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -121,6 +122,8 @@ int rt_add_directional_light(rt_renderer* r, const float d[3], const float c[3])
 {
   if (!r || !d || !c)
     return RTHIP_E_ARG;
+  if (r->generated)
+    return RTHIP_E_STATE; // lights are uploaded with the scene: one added later would silently never shine
   DirectionalLight L;
   L.direction = vec3{d[0], d[1], d[2]};
   L.color = vec3{c[0], c[1], c[2]};
@@ -131,6 +134,8 @@ int rt_add_point_light(rt_renderer* r, const float p[3], const float c[3], float
 {
   if (!r || !p || !c)
     return RTHIP_E_ARG;
+  if (r->generated)
+    return RTHIP_E_STATE;
   PointLight L;
   L.position = vec3{p[0], p[1], p[2]};
   L.color = vec3{c[0], c[1], c[2]};
@@ -176,6 +181,8 @@ int rt_set_option(rt_renderer* r, const char* name, double value)
     o.tileSize = u;
   else if (n == "passesPerCall")
     o.passesPerCall = u;
+  else if (n == "chunkMs")
+    o.chunkMs = (float)std::max(0.1, value);
   else if (n == "referenceEdgeIndexing")
     fo.referenceEdgeIndexing = value != 0;
   else if (n == "maxLeafTriangles")
@@ -295,6 +302,8 @@ int rt_save_image(rt_renderer* r, const char* path, uint32_t width, uint32_t hei
 {
   if (!r || !path || !width || !height)
     return RTHIP_E_ARG;
+  if (width != r->hip->frameWidth() || height != r->hip->frameHeight())
+    return RTHIP_E_ARG; // the read-back below fills the CURRENT frame's width * height pixels
   std::vector<float> rgb((size_t)width * height * 3, 0.0f);
   const int rc = r->hip->readImage(rgb.data());
   return rc ? rc : rt_write_ppm(path, rgb.data(), width, height);
@@ -336,4 +345,9 @@ int rt_get_flat(rt_renderer* r, const rtflat_info** info, const rtflat_model_nod
   return 0;
 }
 rthip_ctx* rt_context(rt_renderer* r) { return r ? r->hip->context() : nullptr; }
+int rt_comm_init(rt_renderer* r, const unsigned char id[RTHIP_COMM_ID_BYTES], int rank, int worldSize)
+{
+  return (r && id) ? r->hip->commInit(id, rank, worldSize) : RTHIP_E_ARG;
+}
+int rt_gather(rt_renderer* r, float* recvDev, uint64_t floatsPerRank, int root) { return r ? r->hip->gather(recvDev, floatsPerRank, root) : RTHIP_E_ARG; }
 }

@@ -48,6 +48,8 @@ int HIPRenderer::beginFrameRender(Camera cam, RenderParameter params)
   error = rthip_begin(ctx, &c, &frame);
   if (error)
     std::fprintf(stderr, "HIPRenderer: rthip_begin: %s\n", rthip_error_string(error));
+  else
+    this->frame = params;
   return error;
 }
 
@@ -73,26 +75,32 @@ int HIPRenderer::enqueuePasses(uint32_t begin, uint32_t count)
 
 int HIPRenderer::synchronize() { return ctx ? (error = rthip_synchronize(ctx)) : (error = RTHIP_E_NODEVICE); }
 
-// Takes the place of CPURenderer::render (src/cpu/CPURenderer.cpp:138-207).  The device keeps the accumulator;
-// per-sample-pass times go to sampleTimes as in the reference (:204-205), here device milliseconds of a call
-// divided evenly over the passes it ran.
+// Takes the place of CPURenderer::render (src/cpu/CPURenderer.cpp:138-207).  The device keeps the accumulator.  `running`
+// is polled before every call (:146) and a call is bounded to about options.chunkMs of device work, so a cancel returns
+// promptly even with main.cpp's 10 000 spp; sampleTimes gets one entry per pass (:204-205): the call's device
+// milliseconds divided over the passes it ran.
 void HIPRenderer::render(Camera cam, RenderParameter params)
 {
   if (beginFrameRender(cam, params))
     return;
   uint32_t samp = 0;
+  uint32_t n = options.passesPerCall ? options.passesPerCall : 1u;
   while (samp < params.numSamples)
   {
     if (!running) // src/cpu/CPURenderer.cpp:146
       return;
-    const uint32_t left = params.numSamples - samp;
-    const uint32_t n = options.passesPerCall ? std::min(options.passesPerCall, left) : left;
+    n = std::min(n, params.numSamples - samp);
     float ms = 0.0f;
     if (renderPasses(samp, n, &ms))
       return;
     for (uint32_t k = 0; k < n; ++k)
       sampleTimes.push_back(ms / float(n));
     samp += n;
+    if (!options.passesPerCall)
+    {
+      const float perPass = std::max(ms / float(n), 1e-3f);
+      n = (uint32_t)std::max(1.0f, std::min(256.0f, options.chunkMs / perPass));
+    }
   }
 }
 } // namespace rt

@@ -14,7 +14,11 @@ struct HIPRenderOptions
   uint32_t aovDepths = 0;       // record hit-id / shadow AOVs for parity checks
   uint32_t tileSize = 64;
   std::vector<uint32_t> tiles;  // empty = whole image; otherwise the tiles this renderer owns (multi-GPU sharding)
-  uint32_t passesPerCall = 0;   // sample passes handed to the device per call (0 = all remaining); `running` is polled between calls
+  // sample passes handed to the device per call; `running` is polled and sampleTimes appended between calls
+  // (src/cpu/CPURenderer.cpp:146,204-205).  0 = adaptive: the first call runs one pass, later calls as many as fit in
+  // about chunkMs of device time, so cancelRender()/startRender() return within that bound whatever the sample budget
+  uint32_t passesPerCall = 0;
+  float chunkMs = 50.0f;
 };
 
 class HIPRenderer : public Renderer
@@ -49,6 +53,13 @@ public:
   // context's stream; synchronize() waits for everything queued so far
   int enqueuePasses(uint32_t begin, uint32_t count);
   int synchronize();
+  uint32_t frameWidth() const { return frame.width; }
+  uint32_t frameHeight() const { return frame.height; }
+
+  // multi-GPU assembly (one renderer per GPU / process): joins an RCCL communicator and gathers the tile-major accumulators
+  // of all ranks on `root` (include/rthip.h: rthip_comm_init, rthip_gather)
+  int commInit(const unsigned char* id, int rank, int worldSize) { return ctx ? (error = rthip_comm_init(ctx, id, rank, worldSize)) : RTHIP_E_NODEVICE; }
+  int gather(float* recvDev, uint64_t floatsPerRank, int root) { return ctx ? (error = rthip_gather(ctx, recvDev, floatsPerRank, root)) : RTHIP_E_NODEVICE; }
 
 protected:
   void render(Camera cam, RenderParameter params) override;
@@ -57,5 +68,6 @@ private:
   rthip_ctx* ctx = nullptr;
   HIPScene* scene = nullptr;
   int error = 0;
+  RenderParameter frame{0, 0, 0}; // of the last beginFrameRender
 };
 } // namespace rt

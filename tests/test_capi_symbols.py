@@ -49,3 +49,24 @@ def test_no_gpu_means_a_loud_error_not_a_fallback():
     with pytest.raises(capi.RtError) as e:
         capi.Renderer("hip")
     assert e.value.code == capi.RTHIP_E_NODEVICE
+
+
+def test_lights_and_meshes_are_refused_after_generate():
+    """Lights are uploaded with the scene (rt_generate): one added later would silently never shine, unlike the reference,
+    which reads its light vectors live (src/cpu/CPUScene.cpp:31,39).  The call says so instead."""
+    import numpy as np
+    r = capi.Renderer("hip-offline")
+    r.add_directional_light((0, -1, 0))
+    r.add_mesh(capi.Mesh.cube())
+    r.generate()
+    import pytest
+    with pytest.raises(capi.RtError) as e:
+        r.add_directional_light((0, -1, 0))
+    assert e.value.code == capi.RTHIP_E_STATE
+    with pytest.raises(capi.RtError) as e:
+        r.add_point_light()
+    assert e.value.code == capi.RTHIP_E_STATE
+    with pytest.raises(capi.RtError) as e:
+        r.add_mesh(capi.Mesh.cube())
+    assert e.value.code == capi.RTHIP_E_STATE
+    r.close()

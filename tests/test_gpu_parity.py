@@ -355,3 +355,67 @@ def test_error_codes_of_the_kernel_abi():
         r.begin_frame(spec.product_camera(), 64, 64, 1)
     assert e.value.code == ra.capi.RTHIP_E_LIMIT
     r.close()
+
+
+def test_cancel_render_returns_promptly_and_the_renderer_stays_usable():
+    """Renderer::startRender with main.cpp's 10 000 spp (src/main.cpp:29): `running` is polled between calls bounded to
+    ~50 ms of device work (src/cpu/CPURenderer.cpp:146), so rt_cancel_render returns at once, sampleTimes holds one entry
+    per pass that ran (:204-205), and the next render is untouched by the cancelled one."""
+    import time
+    spec = scenes.soup_scene(20000, 3, 0.05)
+    W, H, N = 1920, 1080, 10000
+    r = spec.build_product(options=dict(maxDepth=12))
+    r.start_render(spec.product_camera(), W, H, N)
+    time.sleep(0.5)
+    t = time.perf_counter()
+    r.cancel()
+    waited = time.perf_counter() - t
+    ran = len(r.sample_times())
+    assert waited < 0.4, f"cancel took {waited:.3f} s"
+    assert 0 < ran < N, ran
+    assert (r.sample_times() > 0).all()
+    # a fresh render after the cancel gives exactly what a renderer that was never cancelled gives
+    r.render(spec.product_camera(), 160, 120, 3)
+    assert len(r.sample_times()) == 3
+    got = r.accumulator()
+    ref = _render(spec, 160, 120, 3, 12)
+    assert np.array_equal(got.view(np.uint32), ref.accumulator().view(np.uint32))
+    r.close(), ref.close()
+
+
+def test_gather_over_rccl_single_rank_communicator():
+    """rthip_comm_init + rthip_gather with a one-rank communicator: the rank sends its tile-major accumulator to itself through
+    RCCL (grouped ncclSend / ncclRecv), zero-padded to the common per-rank size; re-tiled with rthip_untile it is the frame."""
+    import ctypes as C
+    import torch
+    from raytracer_amd import dist as rdist
+    spec = scenes.bunny_scene()
+    W, H, N, depth = 250, 200, 2, 5
+    r = _render(spec, W, H, N, depth)
+    want = r.accumulator()
+    hl = ra.capi.hip_lib()
+    ident = C.create_string_buffer(ra.capi.RTHIP_COMM_ID_BYTES)
+    assert hl.rthip_comm_unique_id(ident) == 0, ra.capi.error_string(ra.capi.RTHIP_E_COMM)
+    rc = hl.rthip_comm_init(r.context, ident.raw, 0, 1)
+    assert rc == 0, ra.capi.error_string(rc)
+    assert hl.rthip_comm_init(r.context, ident.raw, 0, 1) == ra.capi.RTHIP_E_STATE  # already joined
+    tiles = rdist.assign_tiles(W, H, 1, 64)[0]
+    mine = len(tiles) * 64 * 64 * 3
+    per_rank = mine + 64 * 64 * 3  # as if another rank owned one tile more: this rank's block is zero-padded
+    recv = torch.full((per_rank,), -7.0, dtype=torch.float32, device="cuda:0")
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    rc = hl.rthip_gather(r.context, recv.data_ptr(), per_rank, 0)
+    assert rc == 0, ra.capi.error_string(rc)
+    rc = hl.rthip_untile(r.context, recv.data_ptr(), ra.capi._up(tiles), len(tiles), frame.data_ptr())  # same stream: ordered behind the gather
+    assert rc == 0, ra.capi.error_string(rc)
+    assert hl.rthip_synchronize(r.context) == 0
+    got = recv.cpu().numpy()
+    assert np.array_equal(got[:mine].reshape(-1, 3).view(np.uint32), rdist.to_tile_major(want, tiles).view(np.uint32))
+    assert not got[mine:].any()
+    assert np.array_equal(frame.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert hl.rthip_gather(r.context, None, per_rank, 0) == ra.capi.RTHIP_E_ARG      # the root needs a receive buffer
+    assert hl.rthip_gather(r.context, recv.data_ptr(), 3, 0) == ra.capi.RTHIP_E_ARG   # smaller than this rank's accumulator
+    assert hl.rthip_comm_destroy(r.context) == 0
+    assert hl.rthip_gather(r.context, recv.data_ptr(), per_rank, 0) == ra.capi.RTHIP_E_STATE
+    r.close()

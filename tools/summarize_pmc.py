@@ -52,8 +52,7 @@ def main():
                 per[k][c] += float(row["Counter_Value"])
                 calls[k][c].add((path, row["Dispatch_Id"]))
     out = {}
-    traffic_sum = defaultdict(lambda: [0.0, 0.0, 0, 0])  # key -> [fetch KiB, write KiB, fetch dispatches, write dispatches]
-    valu_sum = defaultdict(lambda: [0.0, 0, 0.0, 0])     # key -> [SQ_INSTS_VALU, dispatches, GRBM_GUI_ACTIVE, dispatches]
+    fam = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))  # family -> counter -> [sum, dispatches]
     for k, cs in per.items():
         if not k.startswith("k_"):
             continue  # torch / runtime kernels
@@ -64,8 +63,6 @@ def main():
         if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
             # lanes active per VALU instruction (of 64): thread-cycles / (instruction-cycles * 64)
             d["valu_lane_utilisation"] = round(g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64.0), 4)
-        if g("SQ_ACTIVE_INST_VALU") and g("SQ_BUSY_CYCLES"):
-            d["valu_busy_share"] = round(g("SQ_ACTIVE_INST_VALU") * 4.0 / g("SQ_BUSY_CYCLES"), 4)  # quad-cycles -> cycles, summed over SQs
         if g("SQ_WAVE_CYCLES") and g("SQ_BUSY_CYCLES"):
             d["mean_waves_resident_per_sq_cycle"] = round(g("SQ_WAVE_CYCLES") * 4.0 / g("SQ_BUSY_CYCLES"), 3)
         if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and (g("TCC_HIT_sum") + g("TCC_MISS_sum")) > 0:
@@ -75,39 +72,54 @@ def main():
             d["fetch_bytes_x2_gfx950"] = g("FETCH_SIZE") * 2048.0
         if g("WRITE_SIZE") is not None:
             d["write_bytes"] = g("WRITE_SIZE") * 1024.0
+        if g("SQ_INSTS_VALU") and g("GRBM_GUI_ACTIVE"):
+            # VALU issue utilisation: a wave64 VALU instruction occupies its SIMD for VALU_CYCLES_PER_INST cycles (measured:
+            # profiles/r02_valu_rate.txt, 2 with several waves per SIMD; quarter-rate and IEEE divide / sqrt sequences take
+            # longer, so this is a lower bound); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            d["valu_issue_utilisation"] = round(g("SQ_INSTS_VALU") * VALU_CYCLES_PER_INST / (NUM_SIMD * g("GRBM_GUI_ACTIVE") / NUM_XCD), 4)
         out[k] = d
         bk = bench_key(k)
         if bk and "COUNT" not in k:
-            t = traffic_sum[bk]
-            if "FETCH_SIZE" in cs:
-                t[0] += cs["FETCH_SIZE"]
-                t[2] += n["FETCH_SIZE"]
-            if "WRITE_SIZE" in cs:
-                t[1] += cs["WRITE_SIZE"]
-                t[3] += n["WRITE_SIZE"]
-            v = valu_sum[bk]
-            if "SQ_INSTS_VALU" in cs:
-                v[0] += cs["SQ_INSTS_VALU"]
-                v[1] += n["SQ_INSTS_VALU"]
-            if "GRBM_GUI_ACTIVE" in cs:
-                v[2] += cs["GRBM_GUI_ACTIVE"]
-                v[3] += n["GRBM_GUI_ACTIVE"]
-    traffic = {k: round(2048.0 * t[0] / t[2] + 1024.0 * t[1] / t[3], 1) for k, t in traffic_sum.items() if t[2] and t[3]}
-    out["_hbm_bytes_per_launch"] = traffic
-    # VALU issue utilisation: wave-instructions x 4 cycles (a wave64 op occupies its 16-lane SIMD for 4 cycles; quarter-rate
-    # ops for longer, so this is a lower bound) over the SIMD-cycles of the launch.  GRBM_GUI_ACTIVE is summed over the 8 XCDs.
-    NUM_SIMD, NUM_XCD = 256 * 4, 8
-    valu = {k: round((v[0] / v[1]) * 4.0 / (NUM_SIMD * (v[2] / v[3]) / NUM_XCD), 4) for k, v in valu_sum.items() if v[1] and v[3] and v[2] > 0}
-    out["_valu_issue_utilisation"] = valu
+            for c in cs:
+                fam[bk][c][0] += cs[c]
+                fam[bk][c][1] += n[c]
+    families = {}
+    for bk, cs in fam.items():
+        a = {c: v[0] / v[1] for c, v in cs.items() if v[1]}
+        e = {}
+        if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
+            e["hbm_bytes_per_launch"] = round(2048.0 * a["FETCH_SIZE"] + 1024.0 * a["WRITE_SIZE"], 1)
+        if "SQ_INSTS_VALU" in a:
+            e["valu_insts_per_launch"] = round(a["SQ_INSTS_VALU"], 1)
+        if "SQ_INSTS_SALU" in a:
+            e["salu_insts_per_launch"] = round(a["SQ_INSTS_SALU"], 1)
+        if a.get("TCC_HIT_sum") is not None and a.get("TCC_MISS_sum") is not None and a["TCC_HIT_sum"] + a["TCC_MISS_sum"] > 0:
+            e["l2_hit_rate"] = round(a["TCC_HIT_sum"] / (a["TCC_HIT_sum"] + a["TCC_MISS_sum"]), 4)
+        if a.get("SQ_THREAD_CYCLES_VALU") and a.get("SQ_ACTIVE_INST_VALU"):
+            e["valu_lane_utilisation"] = round(a["SQ_THREAD_CYCLES_VALU"] / (a["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
+        if a.get("SQ_INSTS_VALU") and a.get("GRBM_GUI_ACTIVE"):
+            e["valu_issue_utilisation_under_pmc"] = round(a["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / (NUM_SIMD * a["GRBM_GUI_ACTIVE"] / NUM_XCD), 4)
+        if a.get("SQ_WAVE_CYCLES"):
+            for c, name in (("SQ_WAIT_ANY", "wave_time_waiting_on_counters"), ("SQ_WAIT_INST_ANY", "wave_time_waiting_to_issue"),
+                            ("SQ_ACTIVE_INST_ANY", "wave_time_issuing")):
+                if a.get(c) is not None:
+                    e[name] = round(a[c] / a["SQ_WAVE_CYCLES"], 4)
+        e["launches_profiled"] = int(max(v[1] for v in cs.values()))
+        families[bk] = e
+    out["_per_kernel_family"] = families
     print(json.dumps(out, indent=1, sort_keys=True))
     if len(sys.argv) >= 5 and sys.argv[2] == "--traffic":
         workload, path = sys.argv[3], sys.argv[4]
         doc = json.load(open(path)) if os.path.exists(path) else {}
-        doc["_note"] = ("HBM bytes per launch from rocprofv3 PMC passes (tools/profile_pmc.sh): 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, "
-                        "averaged over the launches of each kernel family in bench.py runs of the named workload")
-        doc[workload] = traffic
-        doc.setdefault("_valu_issue_utilisation", {})[workload] = valu
+        doc = {k: v for k, v in doc.items() if isinstance(v, dict) and all(isinstance(x, dict) for x in v.values())}  # drop the round-1 layout
+        doc["_note"] = {"text": {"what": "per kernel family of bench.py (extend / shadow / shade / accumulate), averaged over the launches of rocprofv3 --pmc "
+                                 "passes of `bench.py --workload <name>` (tools/profile_pmc.sh): HBM bytes per launch = 2*FETCH_SIZE*1024 + "
+                                 "WRITE_SIZE*1024 (gfx950 correction of MI355X_MICROARCH.md), VALU wave-instructions per launch, L2 hit rate, lane "
+                                 "utilisation; bench.py divides by ITS OWN live launch durations"}}
+        doc[workload] = families
         json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
 
 
+NUM_SIMD, NUM_XCD = 256 * 4, 8
+VALU_CYCLES_PER_INST = 2.0
 main()
