@@ -253,22 +253,49 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameGeom g, PathBuffers 
   float r = 0, gg = 0, b = 0;
   bool loaded = fresh != 0; // 0 + x == x and 0 + 0 == +0: starting from zero is what the cleared accumulator would give
   const float n = float(g.numSamples);
-  for (uint32_t s = 0; s < numBatchSamples; ++s)
-  {
-    const size_t p = slotOf(g, s, j);
-    // kDeadZero: the sample's radiance is exactly +0 (primary miss) -> adding 0/N leaves the sum unchanged
-    if (pb.live[p] != kDead)
-      continue;
+  auto add = [&](float4 v) {
     if (!loaded)
     {
       r = acc[3 * i], gg = acc[3 * i + 1], b = acc[3 * i + 2];
       loaded = true;
     }
-    const float4 v = pb.s0[p];
     r += v.x / n;
     gg += v.y / n;
     b += v.z / n;
+  };
+  if (g.batchLg == 0 && (numBatchSamples & 3u) == 0)
+  {
+    // one pixel per micro-block: this thread's samples are consecutive slots.  Four at a time, so that every 64-byte line
+    // of radiance records (and every word of liveness bytes) is fetched once and used whole -- one record per iteration
+    // made 64 lanes revisit 64 different lines four times over, which the L1 does not hold on to.
+    const size_t first = (size_t)j * numBatchSamples;
+    for (uint32_t s = 0; s < numBatchSamples; s += 4)
+    {
+      const uint32_t lv = *reinterpret_cast<const uint32_t*>(pb.live + first + s);
+      const bool d0 = (lv & 0xffu) == kDead, d1 = ((lv >> 8) & 0xffu) == kDead, d2 = ((lv >> 16) & 0xffu) == kDead, d3 = (lv >> 24) == kDead;
+      if (!(d0 || d1 || d2 || d3))
+        continue;
+      const float4* q = pb.s0 + first + s;
+      const float4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+      if (d0)
+        add(v0);
+      if (d1)
+        add(v1);
+      if (d2)
+        add(v2);
+      if (d3)
+        add(v3);
+    }
   }
+  else
+    for (uint32_t s = 0; s < numBatchSamples; ++s)
+    {
+      const size_t p = slotOf(g, s, j);
+      // kDeadZero: the sample's radiance is exactly +0 (primary miss) -> adding 0/N leaves the sum unchanged
+      if (pb.live[p] != kDead)
+        continue;
+      add(pb.s0[p]);
+    }
   if (loaded)
   {
     acc[3 * i] = r;
