@@ -46,7 +46,8 @@ int rt_add_mesh(rt_renderer*, const rt_mesh*, const float transform[16]);
 int rt_generate(rt_renderer*);                                                 /* Renderer::generate */
 
 /* options the reference hard-codes: name in {"maxDepth","aovDepths","tileSize","passesPerCall","chunkMs",
- * "referenceEdgeIndexing","maxLeafTriangles","sahBins","buildThreads","originBoundScale","countWork","kernelTiming","fusedPrimary","pipelining"};
+ * "referenceEdgeIndexing","maxLeafTriangles","sahBins","buildThreads","originBoundScale","deviceBvh" (1: the triangle-level BVH is
+ * built on the device, rthip_upload_scene_build, instead of by the host's binned-SAH builder),"countWork","kernelTiming","fusedPrimary","pipelining"};
  * scene options must be set before rt_generate */
 int rt_set_option(rt_renderer*, const char* name, double value);
 int rt_set_tiles(rt_renderer*, const uint32_t* tileIds, uint32_t numTiles);    /* tiles this renderer owns; 0 = all */
@@ -77,6 +78,8 @@ int rt_get_kernel_times(rt_renderer*, float msOut[6], uint32_t launchesOut[6]);
 /* the flattened scene (valid after rt_generate, owned by the renderer) */
 int rt_get_flat(rt_renderer*, const rtflat_info** info, const rtflat_model_node** modelNodes, const rtflat_node** nodes,
                 const rtflat_tri** tris, double* buildSeconds);
+/* host seconds of the flattener and device milliseconds of the BVH build (0 unless "deviceBvh" was set) */
+int rt_get_build_times(rt_renderer*, double* hostSeconds, double* deviceMs);
 /* the low-level context, for device-pointer level integration (multi-GPU gather) and probes */
 rthip_ctx* rt_context(rt_renderer*);
 /* multi-GPU assembly, one renderer per GPU / process (forwards to rthip_comm_init / rthip_gather; the id comes from

@@ -86,6 +86,20 @@ int rthip_upload_scene(rthip_ctx* ctx, const rtflat_info* info, const rtflat_mod
                        const rtflat_tri* tris, const rthip_dir_light* dirLights, uint32_t numDirLights,
                        const rthip_point_light* pointLights, uint32_t numPointLights);
 
+/* Same, but the triangle-level BVH is BUILT ON THE DEVICE (Morton codes, radix sort, binary radix tree, bottom-up refit,
+ * collapse into the same quantised 4-wide rtflat_node records).  The caller passes what precedes that step in
+ * CPUScene::createRayTracingHierarchy's place (src/cpu/CPUScene.cpp:67-105): the model-level tree, whose leaves name their
+ * triangles as records [indicesOffset, indicesOffset + triCount) of `trisModelOrder` (one rtflat_tri per triangle in the
+ * order of the scene's pools), and info with numModelNodes, numTris, scene box, padAbs, originBound, cullRel/cullAbs set.
+ * On return modelNodes[].blas, info->numNodes and info->maxDepthBlas describe the tree that was built (rthip_download_scene
+ * fetches the records); buildMsOut (may be NULL) is the device time of the build.  Hit results do not depend on which
+ * builder made the tree. */
+int rthip_upload_scene_build(rthip_ctx* ctx, rtflat_info* info, rtflat_model_node* modelNodes, const rtflat_tri* trisModelOrder,
+                             uint32_t maxLeafTris, const rthip_dir_light* dirLights, uint32_t numDirLights,
+                             const rthip_point_light* pointLights, uint32_t numPointLights, float* buildMsOut);
+/* copies the scene's node / triangle records back from the device (either pointer may be NULL) */
+int rthip_download_scene(rthip_ctx* ctx, rtflat_node* nodesOut, uint32_t nodeCapacity, rtflat_tri* trisOut, uint32_t triCapacity);
+
 /* Starts a frame: allocates and clears accumulator/image for the tiles of `frame`
  * (CPURenderer::render's prologue, src/cpu/CPURenderer.cpp:140-143). */
 int rthip_begin(rthip_ctx* ctx, const rthip_camera* camera, const rthip_frame_desc* frame);

@@ -151,6 +151,7 @@ def host_lib():
         L.rt_get_kernel_times.argtypes = [vp, fp, up]
         L.rt_get_flat.argtypes = [vp, C.POINTER(C.POINTER(FlatInfo)), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_double)]
         L.rt_context.argtypes = [vp]
+        L.rt_get_build_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.rt_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
         L.rt_gather.argtypes = [vp, vp, C.c_uint64, C.c_int]
         _host = L
@@ -376,6 +377,12 @@ class Renderer:
         return dict(_owner=self, info=i, info_bytes=bytes(C.string_at(C.addressof(i), C.sizeof(FlatInfo))),
                     model_nodes=view(mn, i.numModelNodes, MODEL_NODE_DTYPE), nodes=view(nd, max(i.numNodes, 1), NODE_DTYPE),
                     tris=view(tr, max(i.numTris, 1), TRI_DTYPE), build_seconds=secs.value)
+
+    def build_times(self):
+        """(host seconds of the flattener, device milliseconds of the BVH build -- 0 unless option deviceBvh was set)"""
+        a, b = C.c_double(), C.c_double()
+        _check(host_lib().rt_get_build_times(self._h, C.byref(a), C.byref(b)), "rt_get_build_times")
+        return a.value, b.value
 
     @property
     def context(self):

@@ -31,6 +31,8 @@
 #include <new>
 #include <vector>
 
+#include <rocprim/rocprim.hpp> // device radix sort of the Morton codes (rthip_upload_scene_build)
+
 #include "rt_device.h"
 
 using rt::vec3;
@@ -45,6 +47,7 @@ using rtd::CameraConsts;
   } while (0)
 
 #include "rt_kernel_common.h"
+#include "rt_lbvh.h"
 #include "rt_probes.h"
 #include "rt_shade.h"
 #include "rt_trace.h"
@@ -867,8 +870,197 @@ int rthip_upload_scene(rthip_ctx* c, const rtflat_info* info, const rtflat_model
   c->info.maxDepthBlas = deepest;
   c->spillCap = 3 * deepest + 2 > kStackLds ? 3 * deepest + 2 - kStackLds : 1u;
   c->spill.release(); // sized per scene in ensurePathBuffers
+  c->alt.spill.release();
   c->haveScene = true;
   c->haveFrame = false;
+  return 0;
+}
+
+// Uploads the scene's triangles and BUILDS the triangle-level BVH on the device (rt_lbvh.h): Morton codes, radix sort, binary
+// radix tree, level-by-level refit, collapse into the same quantised 4-wide rtflat_node records the host builder writes.
+int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node* modelNodes, const rtflat_tri* trisModelOrder, uint32_t maxLeafTris,
+                             const rthip_dir_light* dirLights, uint32_t numDirLights, const rthip_point_light* pointLights, uint32_t numPointLights,
+                             float* buildMsOut)
+{
+  if (!c || !info || !modelNodes || !trisModelOrder || (numDirLights && !dirLights) || (numPointLights && !pointLights))
+    return RTHIP_E_ARG;
+  if (info->numModelNodes == 0 || info->numTris == 0)
+    return RTHIP_E_ARG;
+  if (numDirLights > kMaxLights || numPointLights > kMaxLights || info->numTris >= (1u << 28) - 1u)
+    return RTHIP_E_LIMIT;
+  const uint32_t maxLeaf = std::max(1u, std::min(maxLeafTris, (uint32_t)RTFLAT_MAX_LEAF_TRIS));
+  const uint32_t numTris = info->numTris;
+  uint32_t largest = 0;
+  for (uint32_t k = 0; k < info->numModelNodes; ++k)
+  {
+    const rtflat_model_node& mn = modelNodes[k];
+    if (mn.subtreeSize == 0 || k + mn.subtreeSize > info->numModelNodes)
+      return RTHIP_E_ARG;
+    if (mn.triCount > 0 && ((uint64_t)mn.indicesOffset + mn.triCount > numTris))
+      return RTHIP_E_ARG; // a model's records are [indicesOffset, indicesOffset + triCount) of the model-order array
+    largest = std::max(largest, mn.triCount);
+  }
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->alt.stream)); // frames still in flight on either slot read the old scene
+  c->altPending = false;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->haveScene = false;
+  c->haveFrame = false;
+  int rc;
+  const uint32_t nodeCap = std::max(1u, numTris);
+  DevBuf<rtflat_tri> trisIn;
+  DevBuf<LbvhBox> primBoxes, innerBoxes;
+  DevBuf<uint64_t> codes, codesSorted;
+  DevBuf<uint32_t> ids, idsSorted, small; // small: [nodeCounter | overflow | level counts (kLevels + 1)]
+  DevBuf<LbvhNode> binary;
+  DevBuf<uint8_t> done, sortTemp;
+  DevBuf<uint2> frontier;
+  constexpr uint32_t kLevels = (kMaxStack - 2) / 3; // deepest chain of 4-wide nodes the traversal stack can take
+  if ((rc = c->modelNodes.ensure(info->numModelNodes)) || (rc = c->nodes.ensure(nodeCap)) || (rc = c->tris.ensure(numTris)) || (rc = c->lights.ensure(1)) ||
+      (rc = trisIn.ensure(numTris)) || (rc = primBoxes.ensure(largest)) || (rc = innerBoxes.ensure(largest)) || (rc = codes.ensure(largest)) ||
+      (rc = codesSorted.ensure(largest)) || (rc = ids.ensure(largest)) || (rc = idsSorted.ensure(largest)) || (rc = binary.ensure(largest)) ||
+      (rc = done.ensure(largest)) || (rc = frontier.ensure(2 * (size_t)largest)) || (rc = small.ensure(2 + kLevels + 2)))
+    return rc;
+  size_t sortBytes = 0;
+  if (rocprim::radix_sort_pairs(nullptr, sortBytes, codes.p, codesSorted.p, ids.p, idsSorted.p, largest, 0, 64, c->stream) != hipSuccess)
+    return RTHIP_E_ARG;
+  if ((rc = sortTemp.ensure(sortBytes)))
+    return rc;
+  HIPCHK(hipMemcpy(trisIn.p, trisModelOrder, sizeof(rtflat_tri) * numTris, hipMemcpyHostToDevice));
+  HIPCHK(hipEventRecord(c->evA, c->stream));
+  uint32_t nodesUsed = 0, deepest = 1;
+  const float3 sceneLo = make_float3(info->sceneLo[0], info->sceneLo[1], info->sceneLo[2]);
+  auto inv = [](float e) { return e > 0.0f ? 1.0f / e : 0.0f; };
+  const float3 sceneInvExt = make_float3(inv(info->sceneHi[0] - info->sceneLo[0]), inv(info->sceneHi[1] - info->sceneLo[1]), inv(info->sceneHi[2] - info->sceneLo[2]));
+  for (uint32_t k = 0; k < info->numModelNodes; ++k)
+  {
+    rtflat_model_node& mn = modelNodes[k];
+    if (mn.triCount == 0)
+      continue;
+    const uint32_t n = mn.triCount, base = mn.indicesOffset;
+    if (n <= maxLeaf)
+    {
+      // a model this small is one leaf: its records stay in model order
+      HIPCHK(hipMemcpyAsync(c->tris.p + base, trisIn.p + base, sizeof(rtflat_tri) * n, hipMemcpyDeviceToDevice, c->stream));
+      mn.blas = rtflat_make_leaf(base, n);
+      continue;
+    }
+    const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
+    hipLaunchKernelGGL(k_lbvh_prims, grid, block, 0, c->stream, trisIn.p + base, n, info->padAbs, sceneLo, sceneInvExt, primBoxes.p, codes.p, ids.p);
+    HIPCHK(hipGetLastError());
+    if (rocprim::radix_sort_pairs(sortTemp.p, sortBytes, codes.p, codesSorted.p, ids.p, idsSorted.p, n, 0, 64, c->stream) != hipSuccess)
+      return RTHIP_E_ARG;
+    hipLaunchKernelGGL(k_lbvh_topology, grid, block, 0, c->stream, codesSorted.p, n, binary.p);
+    HIPCHK(hipGetLastError());
+    // refit: one launch per level of the binary tree, until the root has its box (checked every 8 passes)
+    HIPCHK(hipMemsetAsync(done.p, 0, n - 1, c->stream));
+    bool rooted = false;
+    for (uint32_t pass = 1; pass <= 200 && !rooted; ++pass)
+    {
+      hipLaunchKernelGGL(k_lbvh_refit, dim3((n - 1 + kBlock - 1) / kBlock), block, 0, c->stream, binary.p, n - 1, primBoxes.p, idsSorted.p, innerBoxes.p, done.p, pass);
+      HIPCHK(hipGetLastError());
+      if ((pass & 7u) == 0)
+      {
+        uint8_t flag = 0;
+        HIPCHK(hipMemcpyAsync(&flag, done.p, 1, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        rooted = flag != 0;
+      }
+    }
+    if (!rooted)
+      return RTHIP_E_LIMIT; // deeper than any tree the traversal stack could take
+    // collapse to 4-wide nodes, one launch per level of the wide tree
+    const uint32_t root = nodesUsed;
+    if (root >= nodeCap)
+      return RTHIP_E_LIMIT;
+    {
+      std::vector<uint32_t> init(2 + kLevels + 2, 0u);
+      init[0] = root + 1; // next free node
+      init[2] = 1;        // level 0 holds the root
+      HIPCHK(hipMemcpyAsync(small.p, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+      const uint2 first = make_uint2(0u, root);
+      HIPCHK(hipMemcpyAsync(frontier.p, &first, sizeof(first), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream)); // (the two host sources above are stack / local memory)
+    }
+    LbvhEmitArgs ea;
+    ea.nodes = binary.p, ea.innerBoxes = innerBoxes.p, ea.primBoxes = primBoxes.p, ea.ids = idsSorted.p;
+    ea.out = c->nodes.p, ea.outCapacity = nodeCap, ea.nodeCounter = small.p, ea.overflow = small.p + 1;
+    ea.recordBase = base, ea.maxLeaf = maxLeaf;
+    for (uint32_t level = 0; level <= kLevels; ++level)
+    {
+      ea.frontierIn = frontier.p + (size_t)(level & 1u) * largest;
+      ea.frontierOut = frontier.p + (size_t)((level + 1) & 1u) * largest;
+      ea.countIn = small.p + 2 + level;
+      ea.countOut = small.p + 2 + level + 1;
+      hipLaunchKernelGGL(k_lbvh_emit, dim3(std::min<uint32_t>((n + kBlock - 1) / kBlock, (uint32_t)c->numCUs * 8u)), block, 0, c->stream, ea);
+      HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_lbvh_gather, grid, block, 0, c->stream, trisIn.p + base, idsSorted.p, n, c->tris.p + base);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> fin(2 + kLevels + 2, 0u);
+    HIPCHK(hipMemcpyAsync(fin.data(), small.p, fin.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (fin[1] || fin[2 + kLevels + 1]) // node array overflow, or nodes left beyond the deepest level the stack can take
+      return RTHIP_E_LIMIT;
+    for (uint32_t level = 0; level <= kLevels; ++level)
+      if (fin[2 + level])
+        deepest = std::max(deepest, level + 1);
+    nodesUsed = fin[0];
+    mn.blas = root;
+  }
+  if (nodesUsed == 0)
+  {
+    // every model was a single leaf: keep the node array non-empty (one node without children, as the host builder does)
+    rtflat_node none{};
+    for (int a = 0; a < 3; ++a)
+      for (int k = 0; k < 4; ++k)
+        none.qlo[a][k] = 255, none.qhi[a][k] = 0;
+    for (uint32_t& ch : none.child)
+      ch = RTFLAT_INVALID;
+    none.exp[0] = none.exp[1] = none.exp[2] = 27;
+    HIPCHK(hipMemcpy(c->nodes.p, &none, sizeof(none), hipMemcpyHostToDevice));
+    nodesUsed = 1;
+  }
+  HIPCHK(hipEventRecord(c->evB, c->stream));
+  HIPCHK(hipEventSynchronize(c->evB));
+  if (buildMsOut)
+    HIPCHK(hipEventElapsedTime(buildMsOut, c->evA, c->evB));
+  if (3 * deepest + 2 > kMaxStack)
+    return RTHIP_E_LIMIT;
+  HIPCHK(hipMemcpy(c->modelNodes.p, modelNodes, sizeof(rtflat_model_node) * info->numModelNodes, hipMemcpyHostToDevice));
+  Lights& L = c->hostLights;
+  std::memset(&L, 0, sizeof(L));
+  L.numDir = numDirLights;
+  L.numPoint = numPointLights;
+  for (uint32_t i = 0; i < numDirLights; ++i)
+    L.dir[i] = dirLights[i];
+  for (uint32_t i = 0; i < numPointLights; ++i)
+    L.point[i] = pointLights[i];
+  HIPCHK(hipMemcpy(c->lights.p, &L, sizeof(L), hipMemcpyHostToDevice));
+  info->numNodes = nodesUsed;
+  info->maxDepthBlas = deepest;
+  c->info = *info;
+  c->spillCap = 3 * deepest + 2 > kStackLds ? 3 * deepest + 2 - kStackLds : 1u;
+  c->spill.release(); // sized per scene in ensurePathBuffers
+  c->alt.spill.release();
+  c->haveScene = true;
+  return 0;
+}
+
+// the scene arrays as the device holds them (after rthip_upload_scene_build: what the device built)
+int rthip_download_scene(rthip_ctx* c, rtflat_node* nodesOut, uint32_t nodeCapacity, rtflat_tri* trisOut, uint32_t triCapacity)
+{
+  if (!c || (!nodesOut && !trisOut))
+    return RTHIP_E_ARG;
+  if (!c->haveScene)
+    return RTHIP_E_STATE;
+  if ((nodesOut && nodeCapacity < c->info.numNodes) || (trisOut && triCapacity < c->info.numTris))
+    return RTHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  if (nodesOut)
+    HIPCHK(hipMemcpy(nodesOut, c->nodes.p, sizeof(rtflat_node) * c->info.numNodes, hipMemcpyDeviceToHost));
+  if (trisOut)
+    HIPCHK(hipMemcpy(trisOut, c->tris.p, sizeof(rtflat_tri) * c->info.numTris, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -191,6 +191,8 @@ int rt_set_option(rt_renderer* r, const char* name, double value)
     fo.sahBins = u;
   else if (n == "buildThreads")
     fo.threads = u;
+  else if (n == "deviceBvh")
+    fo.deviceBuild = value != 0;
   else if (n == "originBoundScale")
     fo.originBoundScale = (float)value;
   else if (n == "countWork")
@@ -345,6 +347,17 @@ int rt_get_flat(rt_renderer* r, const rtflat_info** info, const rtflat_model_nod
   return 0;
 }
 rthip_ctx* rt_context(rt_renderer* r) { return r ? r->hip->context() : nullptr; }
+int rt_get_build_times(rt_renderer* r, double* hostSeconds, double* deviceMs)
+{
+  if (!r || !r->generated)
+    return RTHIP_E_STATE;
+  const FlatScene& f = r->hip->getScene()->flattened();
+  if (hostSeconds)
+    *hostSeconds = f.buildSeconds;
+  if (deviceMs)
+    *deviceMs = f.deviceBuildMs;
+  return 0;
+}
 int rt_comm_init(rt_renderer* r, const unsigned char id[RTHIP_COMM_ID_BYTES], int rank, int worldSize)
 {
   return (r && id) ? r->hip->commInit(id, rank, worldSize) : RTHIP_E_ARG;

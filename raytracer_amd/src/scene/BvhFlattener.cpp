@@ -502,13 +502,13 @@ FlatScene flattenScene(const ScenePoolsView& pools, const FlattenOptions& opt)
   }
 
   // ---- build one BVH per model into a scratch pool, then emit pre-order
-  std::vector<BinaryNode> scratch(std::max(1u, totalTris));
+  std::vector<BinaryNode> scratch(opt.deviceBuild ? 1u : std::max(1u, totalTris));
   std::atomic<uint32_t> nextNode{0};
   uint32_t threads = opt.threads ? opt.threads : std::thread::hardware_concurrency();
   threads = std::max(1u, std::min(threads, 16u));
   uint32_t deepest = 0;
   std::vector<uint32_t> blasRoot(numModels, RTFLAT_INVALID);
-  for (size_t m = 0; m < numModels; ++m)
+  for (size_t m = 0; m < numModels && !opt.deviceBuild; ++m)
   {
     const ModelReference& r = refs[m];
     if (r.numIndices == 0)

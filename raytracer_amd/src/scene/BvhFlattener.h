@@ -25,6 +25,9 @@ struct FlattenOptions
   float padUlps = 16.0f;         // box padding in units of 2^-24 * (largest coordinate magnitude a ray can see)
   float cullRel = 1.0f / 4096.0f;
   uint32_t threads = 0;          // 0 = hardware concurrency, capped at 16
+  // true: stop before step 2 -- the triangle-level BVH is built on the device (rthip_upload_scene_build); the records of
+  // step 3 are then written in the order of the scene's pools and the node array holds a single childless node
+  bool deviceBuild = false;
 };
 
 struct FlatScene
@@ -33,7 +36,8 @@ struct FlatScene
   std::vector<rtflat_node> nodes;
   std::vector<rtflat_tri> tris;
   rtflat_info info{};
-  double buildSeconds = 0.0;
+  double buildSeconds = 0.0;   // host time of flattenScene
+  double deviceBuildMs = 0.0;  // device time of the BVH build when it ran there (0 otherwise)
 };
 
 struct ScenePoolsView
