@@ -59,7 +59,7 @@ KERNEL_NAMES = {"extend": "k_trace<PRIMARY|CLOSEST> (extend)", "shadow": "k_trac
                 "accumulate": "k_accumulate"}
 
 
-def roofline_block(workload, ktimes, wc, spp):
+def roofline_block(workload, ktimes, wc, spp, ktimes_alone=None):
     """roofline of the dominant kernel family.  `achieved` is ALGORITHMIC bytes per launch / average launch duration
     (per ray 32 B ray record + 16 B hit record (any-hit: 4) + 64 B per node and per triangle record visited,
     counted by the device).  Next to it: the HBM bytes the counters saw (profiles/traffic.json, from rocprofv3 --pmc passes
@@ -97,7 +97,17 @@ def roofline_block(workload, ktimes, wc, spp):
     bound = None
     if hbm_frac is not None and valu_frac is not None:
         bound = "hbm" if hbm_frac >= valu_frac else "valu"
-    return {"bound": bound, "kernel": KERNEL_NAMES[dominant], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    alone = None
+    if ktimes_alone and ktimes_alone.get(dominant, (0, 0))[0] > 0:
+        a_ms, a_launches = ktimes_alone[dominant]
+        a_launch_s = a_ms * 1e-3 / max(1, a_launches)
+        alone = {"avg_launch_ms": round(a_ms / max(1, a_launches), 5), "achieved": round(alg_bytes[dominant] / (a_ms * 1e-3) / 1e9, 2),
+                 "frac": round(alg_bytes[dominant] / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "frac_of_hbm_peak_counters": round(traffic / a_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                 "frac_of_valu_peak": round(valu_insts / a_launch_s / 1e9 / VALU_PEAK_GINST, 4) if valu_insts else None,
+                 "kernel_ms_per_step": {k: round(v[0], 4) for k, v in ktimes_alone.items() if k in alg_bytes},
+                 "note": "one batch at a time, one stream: every kernel has the GPU to itself"}
+    return {"bound": bound, "kernel": KERNEL_NAMES[dominant], "alone": alone, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "hbm_counters": {"bytes_per_launch": traffic, "GB/s": round(traffic / launch_s / 1e9, 1) if traffic else None,
                              "frac_of_hbm_peak": round(hbm_frac, 4) if hbm_frac is not None else None,
@@ -197,6 +207,7 @@ def main():
 
     r = spec.build_product(options=dict(maxDepth=max_depth), device=local_rank)
     flat = r.flat()
+    num_tris, num_nodes = int(flat["info"].numTris), int(flat["info"].numNodes)
     assignment = rdist.assign_tiles(width, height, world, ts)
     if world > 1:
         r.set_tiles(assignment[rank])
@@ -385,12 +396,44 @@ def main():
         r.enqueue_passes(0, spp)
     ktimes = {k: (ms / T, launches / T) for k, (ms, launches) in r.kernel_times().items()}
     r.set_option("kernelTiming", 0)
+    # the same kernels with the GPU to themselves (one slot, one stream): what each achieves when nothing shares the chip
+    r.set_option("pipelining", 0)
+    r.set_option("overlapShadow", 0)
+    r.set_option("kernelTiming", 1)
+    r.begin_frame(cam, width, height, spp)
+    r.render_passes(0, spp)
+    ktimes_alone = dict(r.kernel_times())
+    r.set_option("kernelTiming", 0)
+    r.set_option("pipelining", 1)
+    r.set_option("overlapShadow", 1)
     r.set_option("countWork", 1)
     r.begin_frame(cam, width, height, spp)
     r.render_passes(0, spp)
     wc = r.counters()
     r.set_option("countWork", 0)
-    roofline = roofline_block(args.workload, ktimes, wc, spp)
+    roofline = roofline_block(args.workload, ktimes, wc, spp, ktimes_alone)
+
+    # ---- the same scene through the DEVICE-built BVH (rthip_upload_scene_build): build time and frame time, untimed extra
+    device_bvh = None
+    if world == 1:
+        flat = dict(flat, model_nodes=flat["model_nodes"].copy(), nodes=flat["nodes"].copy(), tris=flat["tris"].copy(), _owner=None)
+        r.close()
+        r2 = spec.build_product(options=dict(maxDepth=max_depth, deviceBvh=1), device=local_rank)
+        host_s, device_ms = r2.build_times()
+        f2 = r2.flat()["info"]
+        for _ in range(2):
+            r2.begin_frame(cam, width, height, spp)
+            r2.enqueue_passes(0, spp)
+        r2.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            r2.begin_frame(cam, width, height, spp)
+            r2.enqueue_passes(0, spp)
+        r2.synchronize()
+        device_bvh = {"build_ms_on_device": round(device_ms, 3), "host_flatten_seconds": round(host_s, 3), "bvh_nodes": int(f2.numNodes),
+                      "ms_per_step": round((time.perf_counter() - t1) / 3 * 1e3, 4),
+                      "note": "Morton LBVH built on the GPU; the timed steps above use the host's binned-SAH tree (better tree, slower build)"}
+        r2.close()
 
     cpu = None
     if not args.no_cpu_baseline:
@@ -400,7 +443,7 @@ def main():
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": wl["name"], "width": width, "height": height, "spp": spp, "max_depth": max_depth,
-                      "tris": int(flat["info"].numTris), "bvh_nodes": int(flat["info"].numNodes), "bvh_build_seconds": round(float(flat["build_seconds"]), 3),
+                      "tris": num_tris, "bvh_nodes": num_nodes, "bvh_build_seconds": round(float(flat["build_seconds"]), 3), "device_bvh": device_bvh,
                       "rays_per_step": int(rays_frame), "primary": int(t[2]), "secondary_extend": int(t[3]), "shadow": int(t[4]),
                       "parallelism": (f"tiles64-{'dynamic' if dynamic else 'rr'}-x{world}-{backend}-{'rthip_gather' if native_gather else 'torch_gather'}"
                                       if world > 1 else "single"),

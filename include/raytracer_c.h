@@ -47,7 +47,7 @@ int rt_generate(rt_renderer*);                                                 /
 
 /* options the reference hard-codes: name in {"maxDepth","aovDepths","tileSize","passesPerCall","chunkMs",
  * "referenceEdgeIndexing","maxLeafTriangles","sahBins","buildThreads","originBoundScale","deviceBvh" (1: the triangle-level BVH is
- * built on the device, rthip_upload_scene_build, instead of by the host's binned-SAH builder),"countWork","kernelTiming","fusedPrimary","pipelining"};
+ * built on the device, rthip_upload_scene_build, instead of by the host's binned-SAH builder),"countWork","kernelTiming","fusedPrimary","pipelining","overlapShadow"};
  * scene options must be set before rt_generate */
 int rt_set_option(rt_renderer*, const char* name, double value);
 int rt_set_tiles(rt_renderer*, const uint32_t* tileIds, uint32_t numTiles);    /* tiles this renderer owns; 0 = all */

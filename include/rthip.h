@@ -155,9 +155,13 @@ int rthip_set_work_counting(rthip_ctx* ctx, int enabled);
 /* 1 (default): primary rays are generated inside the depth-0 extend kernel and never stored;
  * 0: a stand-alone generate kernel writes them first (the A/B baseline) */
 int rthip_set_fused_primary(rthip_ctx* ctx, int enabled);
-/* 1 (default): with a depth cap of 1 a call's passes are split in two pieces that run on two sets of path buffers and two
- * streams, and consecutive frames overlap; 0: one batch at a time (the A/B baseline; results are bit-identical) */
+/* 1 (default): launch batches alternate between two sets of path buffers and streams (two batches in flight, at any depth
+ * cap, across calls and frames); 0: one batch at a time (the A/B baseline; results are bit-identical).  Takes effect at
+ * the next rthip_begin. */
 int rthip_set_pipelining(rthip_ctx* ctx, int enabled);
+/* 1 (default): a depth's shadow and closest-hit launches go to two streams (their tails overlap); 0: one after the other
+ * (with rthip_set_pipelining(ctx, 0) every kernel then runs alone: the A/B baseline and the way to time a kernel by itself) */
+int rthip_set_overlap_shadow(rthip_ctx* ctx, int enabled);
 /* per-kernel device milliseconds and launch counts accumulated since timing was last switched on (HIP event pairs recorded
  * around every launch on the stream it goes to, resolved when the times are read, so batches and frames overlap exactly as
  * they do untimed): order generate, extend, shade, shadow, accumulate, compact.  rthip_set_kernel_timing(ctx,1) starts a

@@ -1523,6 +1523,14 @@ int rthip_set_pipelining(rthip_ctx* c, int enabled)
   return 0;
 }
 
+int rthip_set_overlap_shadow(rthip_ctx* c, int enabled)
+{
+  if (!c)
+    return RTHIP_E_ARG;
+  c->overlapShadow = enabled ? 1u : 0u;
+  return 0;
+}
+
 int rthip_set_kernel_timing(rthip_ctx* c, int enabled)
 {
   if (!c)

@@ -201,6 +201,8 @@ int rt_set_option(rt_renderer* r, const char* name, double value)
     return r->hip->context() ? rthip_set_fused_primary(r->hip->context(), value != 0) : RTHIP_E_NODEVICE;
   else if (n == "pipelining")
     return r->hip->context() ? rthip_set_pipelining(r->hip->context(), value != 0) : RTHIP_E_NODEVICE;
+  else if (n == "overlapShadow")
+    return r->hip->context() ? rthip_set_overlap_shadow(r->hip->context(), value != 0) : RTHIP_E_NODEVICE;
   else if (n == "kernelTiming")
     return r->hip->context() ? rthip_set_kernel_timing(r->hip->context(), value != 0) : RTHIP_E_NODEVICE;
   else

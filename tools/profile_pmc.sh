@@ -17,4 +17,4 @@ run tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum &&
 run tcc2 FETCH_SIZE &&
 run tcc3 WRITE_SIZE &&
 python3 tools/summarize_pmc.py $OUT --traffic $WL profiles/traffic.json > profiles/${TAG}_${WL}_pmc.json && python3 -c "
-import json;d=json.load(open('profiles/${TAG}_${WL}_pmc.json'));print(json.dumps(d['_hbm_bytes_per_launch']))"
+import json;d=json.load(open('profiles/${TAG}_${WL}_pmc.json'));print(json.dumps(d['_per_kernel_family']))"
