@@ -15,7 +15,8 @@ constexpr uint32_t kWavesPerBlock = kBlock / 64;
 constexpr uint32_t kChunk = 512;       // work items a wave scans and compacts at a time
 constexpr uint32_t kStackLds = 16;     // stack entries per lane kept in LDS
 constexpr uint32_t kMaxStack = 96;     // deepest triangle BVH accepted (LDS part + spill)
-constexpr uint32_t kLeafTrigger = 4;    // lanes that must be waiting on a leaf before a wave takes a leaf step (tuned on the 1M soup)
+constexpr uint32_t kLeafTrigger = 4;    // lanes that must be waiting on a leaf before a wave takes a leaf step (once no more arrive)
+constexpr uint32_t kLeafTriggerHi = 24; // ... or takes it regardless (see the leaf-step rule in k_trace)
 constexpr uint32_t kDone = 0xffffffffu; // `cur`: the ray has no node, leaf or model left (== RTFLAT_INVALID)
 constexpr uint32_t kNone = 0xfffffffeu; // `cur` / `postponed`: empty
 constexpr uint32_t kRefillThreshold = 16; // refill once this many lanes are idle (or no lane is active)

@@ -186,7 +186,7 @@ struct rthip_ctx
   uint32_t tuneBlocks = 6;
   uint32_t overlapShadow = 1;    // run a depth's shadow and closest-hit launches on two streams (their tails overlap)
   uint32_t tuneSteal = 1; // spans a wave may pull chunks from (1 = its own only; stealing measured +4% on the 1M soup, -4% on the bunny: off)
-  uint32_t tuneRefill = kRefillThreshold, tuneLeaf = kLeafTrigger;
+  uint32_t tuneRefill = kRefillThreshold, tuneLeaf = kLeafTrigger, tuneLeafHi = kLeafTriggerHi;
   bool fusedPrimary = true;      // generate rays inside the depth-0 traversal kernel instead of storing them
   uint32_t lastBatchBegin = 0, lastBatchCount = 0, lastSamp = 0;
   bool renderedAny = false;
@@ -433,6 +433,7 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   a.anyOut = c->anyOut.p;
   a.refillAt = c->tuneRefill;
   a.leafTrigger = c->tuneLeaf;
+  a.leafTriggerHi = c->tuneLeafHi;
   a.stealSpans = c->tuneSteal;
   a.foldFinal = foldFinal ? 1u : 0u;
   a.aovDepths = c->aovDepths;
@@ -694,8 +695,10 @@ static int createContext(rthip_ctx* c, int device)
   c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* t = getenv("RTHIP_TUNE")) // "refill,leaf[,blocksPerCU]" -- tuning experiments only
   {
-    unsigned r = 0, l = 0, b = 0, st = 1, ov = 1, pl = 1;
-    const int n = sscanf(t, "%u,%u,%u,%u,%u,%u", &r, &l, &b, &st, &ov, &pl);
+    unsigned r = 0, l = 0, b = 0, st = 1, ov = 1, pl = 1, lh = 0;
+    const int n = sscanf(t, "%u,%u,%u,%u,%u,%u,%u", &r, &l, &b, &st, &ov, &pl, &lh);
+    if (n >= 7 && lh >= 1 && lh <= 64)
+      c->tuneLeafHi = lh;
     if (n >= 2 && r >= 1 && r <= 64 && l >= 1 && l <= 64)
       c->tuneRefill = r, c->tuneLeaf = l;
     if (n >= 3 && b >= 1 && b <= 8)

@@ -1,7 +1,9 @@
-#!/bin/bash
-# Runs tests/tune_probe.py once per RTHIP_TUNE setting given on the command line ("refill,leaf[,blocksPerCU[,steal[,overlap[,pieces]]]]"),
-# e.g.  gpurun -- 'bash tools/sweep_tune.sh 16,4 8,4 16,4,4 > gpurun_out/sweep.log'.  Workloads: env PROBE (default "soup1 soup8 bunny").
-# Experiments only; every GPU step has its own time limit and the sweep stops at the first failure.
-for t in "$@"; do
-  RTHIP_TUNE=$t timeout -k 10 240 python3 -u tests/tune_probe.py ${PROBE:-soup1 soup8 bunny} || exit 1
+# frame time of a workload against the refill / leaf-step thresholds of the traversal kernel
+# (RTHIP_TUNE = refill,leafLo,blocksPerCU,steal,overlapShadow,pipeline,leafHi)
+WL=${1:-hf10m}; FR=${2:-2}
+for cfg in "4 24" "4 16" "4 32" "8 24" "2 24" "4 4" "24 24"; do
+  set -- $cfg
+  export RTHIP_TUNE=16,$1,6,0,1,2,$2
+  echo "== leaf lo,hi = $1,$2"
+  timeout -k 10 120 python tools/kernel_probe.py $WL $FR 2>&1 | grep "pipelining=1"
 done
