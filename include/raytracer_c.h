@@ -33,6 +33,16 @@ rt_mesh* rt_mesh_from_arrays(const float* positions, uint32_t numPositions, cons
 uint32_t rt_mesh_num_positions(const rt_mesh*);
 uint32_t rt_mesh_num_triangles(const rt_mesh*);
 void rt_mesh_copy(const rt_mesh*, float* positions3, uint32_t* indices3);
+void rt_mesh_copy_texcoords(const rt_mesh*, float* texCoords2);               /* Model::texCoords, one pair per position */
+/* The mesh's Material (src/util/Material.h:7-14), read by the path only when the scene option "materials" is set.
+ * kind 0 = Material::evaluate as the reference has it (src/util/Material.cpp:4-12: albedo = (u, v, 0), emissive 0; factors
+ * and textures ignored); kind 1 = albedo = baseColor [* albedo texture], emissive = emissive [* emissive texture].
+ * Textures are w*h RGB float triples, row-major, sampled like src/util/Texture.cpp:3-8 (NULL = none); copied.
+ * A mesh that never had a material set has kind 1, baseColor (0,1,0), emissive 0: the constants of CPUScene.cpp:245-246.
+ * Loaded .glb meshes arrive with their primitive's baseColorFactor / emissiveFactor (images are not decoded). */
+int rt_mesh_set_material(rt_mesh*, uint32_t kind, const float baseColor[3], const float emissive[3], const float* albedoTexels,
+                         uint32_t albedoW, uint32_t albedoH, const float* emissiveTexels, uint32_t emissiveW, uint32_t emissiveH);
+int rt_mesh_get_material(const rt_mesh*, uint32_t* kind, float baseColor[3], float emissive[3]);
 void rt_mesh_destroy(rt_mesh*);
 
 /* ---- renderer: Renderer (src/scene/Renderer.h:14-42) with backend "hip" ---- */
@@ -46,7 +56,9 @@ int rt_add_mesh(rt_renderer*, const rt_mesh*, const float transform[16]);
 int rt_generate(rt_renderer*);                                                 /* Renderer::generate */
 
 /* options the reference hard-codes: name in {"maxDepth","aovDepths","tileSize","passesPerCall","chunkMs",
- * "referenceEdgeIndexing","maxLeafTriangles","sahBins","buildThreads","originBoundScale","deviceBvh" (1: the triangle-level BVH is
+ * "referenceEdgeIndexing","maxLeafTriangles","sahBins","buildThreads","originBoundScale","materials" (1: a hit's albedo / emissive come
+ * from its mesh's material instead of the constants of src/cpu/CPUScene.cpp:243-247), "pointShadows" (1: point lights cast shadow
+ * rays as in src/metal/Compute.metal:238-254; needs <= 8 lights in all), "deviceBvh" (1: the triangle-level BVH is
  * built on the device, rthip_upload_scene_build, instead of by the host's binned-SAH builder),"countWork","kernelTiming","fusedPrimary","pipelining","overlapShadow"};
  * scene options must be set before rt_generate */
 int rt_set_option(rt_renderer*, const char* name, double value);
@@ -78,6 +90,9 @@ int rt_get_kernel_times(rt_renderer*, float msOut[6], uint32_t launchesOut[6]);
 /* the flattened scene (valid after rt_generate, owned by the renderer) */
 int rt_get_flat(rt_renderer*, const rtflat_info** info, const rtflat_model_node** modelNodes, const rtflat_node** nodes,
                 const rtflat_tri** tris, double* buildSeconds);
+/* the shading tables handed to rthip_upload_materials (NULL / 0 unless the scene option "materials" was set) */
+int rt_get_flat_shading(rt_renderer*, const rtflat_shade** shade, const rtflat_material** materials, uint32_t* numMaterials,
+                        const float** texels, uint64_t* numTexels);
 /* host seconds of the flattener and device milliseconds of the BVH build (0 unless "deviceBvh" was set) */
 int rt_get_build_times(rt_renderer*, double* hostSeconds, double* deviceMs);
 /* the low-level context, for device-pointer level integration (multi-GPU gather) and probes */

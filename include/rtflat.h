@@ -103,6 +103,35 @@ typedef struct rtflat_tri
   uint32_t pad[2];
 } rtflat_tri;
 
+/* ---- shading inputs (optional: without them every surface has the reference intersector's hard-coded albedo (0,1,0),
+ * src/cpu/CPUScene.cpp:243-247).  Kept apart from the 64-byte triangle records on purpose: traversal never reads them,
+ * only the shade kernel does, once per hit. ---- */
+
+/* per-triangle shading record, 32 B, indexed by triId (= pool order, so a BVH rebuilt on the device keeps it valid):
+ * the texture coordinates of the triangle's three corners (texCoordsPool[positionOffset + idx.x / .y / .z],
+ * src/cpu/CPUScene.cpp:201-203) and the model's material */
+typedef struct rtflat_shade
+{
+  float uv[3][2];
+  uint32_t material; /* index into rtflat_material[] */
+  uint32_t pad;
+} rtflat_shade;
+
+#define RTFLAT_MAT_STUB 0u    /* src/util/Material.cpp:4-12 as it stands: albedo = (u, v, 0), emissive = 0 */
+#define RTFLAT_MAT_FACTORS 1u /* albedo = baseColor [* albedo texture], emissive = emissive [* emissive texture] */
+
+/* material, 64 B.  A texture is `w * h` RGB float triples in the texel pool starting at triple `texel`, row-major,
+ * sampled as src/util/Texture.cpp:3-8 does (nearest texel, x = uint(u * w), y = uint(v * h), no wrap); w == 0: none */
+typedef struct rtflat_material
+{
+  float baseColor[3];
+  uint32_t kind;
+  float emissive[3];
+  uint32_t pad0;
+  uint32_t albedoTexel, albedoW, albedoH, pad1;
+  uint32_t emissiveTexel, emissiveW, emissiveH, pad2;
+} rtflat_material;
+
 /* scene-wide constants the traversal needs */
 typedef struct rtflat_info
 {

@@ -100,6 +100,21 @@ int rthip_upload_scene_build(rthip_ctx* ctx, rtflat_info* info, rtflat_model_nod
 /* copies the scene's node / triangle records back from the device (either pointer may be NULL) */
 int rthip_download_scene(rthip_ctx* ctx, rtflat_node* nodesOut, uint32_t nodeCapacity, rtflat_tri* trisOut, uint32_t triCapacity);
 
+/* Materials on the hot path.  Until this is called every hit has the albedo (0,1,0) and emissive 0 that
+ * the reference's intersector hard-codes (src/cpu/CPUScene.cpp:243-247); afterwards a hit's BRDF is its model's material
+ * evaluated at the interpolated texture coordinates (the evident intent of src/util/Material.cpp:4-12 and
+ * src/util/Texture.cpp:3-8, which the reference never wires in): albedo drives the throughput, the russian-roulette
+ * probability (CPUScene.cpp:13) and the direct light (BRDF.cpp:4-14), emissive is added where the camera sees it
+ * (CPUScene.cpp:27).  `shade` has one record per triangle of the uploaded scene, indexed by triId; `texels` holds
+ * numTexels RGB float triples.  Copies everything; a later rthip_upload_scene* drops the materials again. */
+int rthip_upload_materials(rthip_ctx* ctx, const rtflat_shade* shade, uint32_t numTris, const rtflat_material* materials,
+                           uint32_t numMaterials, const float* texels, uint64_t numTexels);
+/* on != 0: point lights cast shadow rays too, the way the reference's Metal kernel does (src/metal/Compute.metal:238-254:
+ * origin = hit + normal * 1e-3, direction = light - hit, t in [0, 1]); the CPU path leaves them unshadowed
+ * (src/cpu/CPUScene.cpp:42, commented out) and so does this backend by default.  Occlusion bits of the point lights
+ * follow those of the directional lights in the shadow AOV, so on requires numDir + numPoint <= 8 (RTHIP_E_LIMIT). */
+int rthip_set_point_shadows(rthip_ctx* ctx, int on);
+
 /* Starts a frame: allocates and clears accumulator/image for the tiles of `frame`
  * (CPURenderer::render's prologue, src/cpu/CPURenderer.cpp:140-143). */
 int rthip_begin(rthip_ctx* ctx, const rthip_camera* camera, const rthip_frame_desc* frame);

@@ -57,6 +57,9 @@ def lib():
         L.orc_add_point_light.argtypes = [C.c_void_p, fp, fp, C.c_float]
         L.orc_add_model.argtypes = [C.c_void_p, fp, C.c_uint32, fp, C.POINTER(C.c_uint32), C.c_uint32, fp]
         L.orc_generate.argtypes = [C.c_void_p]
+        L.orc_set_model_material.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, fp, fp, fp, C.c_uint32, C.c_uint32, fp, C.c_uint32, C.c_uint32]
+        L.orc_set_shading.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_set_flat_shading.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_num_tris.restype = C.c_uint32
         L.orc_num_tris.argtypes = [C.c_void_p]
         L.orc_num_models.restype = C.c_uint32
@@ -136,6 +139,29 @@ class OracleScene:
             tca = np.ascontiguousarray(texcoords, dtype=np.float32).reshape(-1, 2)
             tc = _fptr(tca)
         lib().orc_add_model(self._h, _fptr(p), p.shape[0], tc, i.ctypes.data_as(C.POINTER(C.c_uint32)), i.shape[0], _fptr(t))
+
+    def set_model_material(self, model_index, kind=1, base_color=(0, 1, 0), emissive=(0, 0, 0), albedo_texture=None,
+                           emissive_texture=None):
+        """Textures: float32 arrays [h, w, 3] or None."""
+        def tex(t):
+            if t is None:
+                return None, 0, 0
+            a = np.ascontiguousarray(t, dtype=np.float32)
+            assert a.ndim == 3 and a.shape[2] == 3
+            return _fptr(a), a.shape[1], a.shape[0]
+        ap, aw, ah = tex(albedo_texture)
+        ep, ew, eh = tex(emissive_texture)
+        lib().orc_set_model_material(self._h, int(model_index), int(kind), _f3(base_color), _f3(emissive), ap, aw, ah, ep, ew, eh)
+
+    def set_shading(self, materials=False, point_shadows=False):
+        lib().orc_set_shading(self._h, 1 if materials else 0, 1 if point_shadows else 0)
+
+    def set_flat_shading(self, shade, materials, texels):
+        """The flattened shading tables (numpy arrays of 32-byte / 64-byte records, float32 texels) for variant B."""
+        keep = [np.ascontiguousarray(shade), np.ascontiguousarray(materials),
+                np.ascontiguousarray(texels if texels is not None and len(texels) else np.zeros(3, np.float32))]
+        self._keep_shading = keep
+        lib().orc_set_flat_shading(self._h, *[a.ctypes.data for a in keep])
 
     def generate(self):
         lib().orc_generate(self._h)

@@ -106,12 +106,61 @@ bool boxHit(const Box& b, const RayO& ray, float tmin, float tmax)
   return tmin < tmax;
 }
 
+// src/util/Texture.h:8-16
+struct TextureData
+{
+  std::vector<V3> textureData;
+  int width = 0, height = 0;
+  // Texture.cpp:3-8: `uint32_t x = texCoords.x * width` (int -> float, float multiply, truncation), row-major fetch.
+  // The reference indexes unchecked; outside [0,1) this restatement clamps to the edge texels (NaN -> texel 0), the
+  // convention include/rthip.h documents for rthip_upload_materials.
+  static uint32_t texel(float coord, int size)
+  {
+    const float f = coord * (float)size;
+    if (!(f >= 0.0f))
+      return 0u;
+    if (f >= (float)size)
+      return (uint32_t)size - 1u;
+    return (uint32_t)f;
+  }
+  V3 sample(V2 texCoords) const
+  {
+    const uint32_t x = texel(texCoords.x, width);
+    const uint32_t y = texel(texCoords.y, height);
+    return textureData[(size_t)y * (size_t)width + x];
+  }
+};
+// src/util/Material.h:7-14.  kind 0 is Material::evaluate exactly as the reference has it (Material.cpp:4-12); kind 1 is
+// the wiring the class is evidently meant for: factor [* texture sample] for albedo and emissive.
+struct MaterialData
+{
+  uint32_t kind = 1;
+  V3 baseColor = {0.0f, 1.0f, 0.0f}, emissiveFactor = {0.0f, 0.0f, 0.0f}; // CPUScene.cpp:245-246
+  std::shared_ptr<TextureData> albedoTexture, emissiveTexture;
+  void evaluate(V2 texCoords, V3& albedo, V3& emissive) const
+  {
+    if (kind == 0)
+    {
+      albedo = V3{texCoords.x, texCoords.y, 0.0f}; // glm::vec3(hitInfo.texCoords, 0)
+      emissive = V3{0.0f, 0.0f, 0.0f};
+      return;
+    }
+    albedo = baseColor;
+    emissive = emissiveFactor;
+    if (albedoTexture)
+      albedo = albedo * albedoTexture->sample(texCoords);
+    if (emissiveTexture)
+      emissive = emissive * emissiveTexture->sample(texCoords);
+  }
+};
+
 struct ModelData // src/util/Model.h:13-24
 {
   Box bbox;
   std::vector<V3> positions, normals, edges, faceNormals;
   std::vector<V2> texCoords;
   std::vector<U3> indices;
+  MaterialData material;
 };
 
 struct TreeNode // src/cpu/CPUScene.h:11-19
@@ -157,6 +206,12 @@ struct orc_scene
   const rtflat_node* fNodes = nullptr;
   const rtflat_tri* fTris = nullptr;
   rtflat_info fInfo{};
+  // shading beyond the reference's CPU path (both off = that path as it stands)
+  bool materialsOn = false;  // a hit's albedo / emissive come from its model's material instead of CPUScene.cpp:243-247
+  bool pointShadows = false; // point lights cast shadow rays as in src/metal/Compute.metal:238-254
+  const rtflat_shade* fShade = nullptr; // variant B reads the flattened shading tables (include/rtflat.h)
+  const rtflat_material* fMaterials = nullptr;
+  const float* fTexels = nullptr;
 
   // ---------------------------------------------------------- scene build
   // Model.cpp:3-26
@@ -284,7 +339,7 @@ struct orc_scene
     return true;
   }
   // CPUScene.cpp:187-252
-  Hit scanModelClosest(const ModelRef& r, const RayO& ray, float tmin, float tmax, Counters& cnt) const
+  Hit scanModelClosest(const ModelRef& r, uint32_t modelIndex, const RayO& ray, float tmin, float tmax, Counters& cnt) const
   {
     Hit best;
     for (size_t i = 0; i < r.numIndices; ++i)
@@ -303,6 +358,8 @@ struct orc_scene
       best.texCoords = uv;
       best.albedo = V3{0.0f, 1.0f, 0.0f}; // :245
       best.emissive = V3{0.0f, 0.0f, 0.0f};
+      if (materialsOn)
+        models[modelIndex]->material.evaluate(uv, best.albedo, best.emissive);
       best.triId = r.indicesOffset + (uint32_t)i;
     }
     return best;
@@ -326,7 +383,7 @@ struct orc_scene
     if (!boxHit(node->box, ray, tmin, tmax))
       return Hit{};
     if (node->model.numIndices > 0)
-      return scanModelClosest(node->model, ray, tmin, tmax, cnt);
+      return scanModelClosest(node->model, node->modelIndex, ray, tmin, tmax, cnt);
     Hit l = closestA(node->left.get(), ray, tmin, tmax, cnt);
     Hit r = closestA(node->right.get(), ray, tmin, tmax, cnt);
     return l.t < r.t ? l : r; // :136 -- right wins unless left is strictly nearer
@@ -570,7 +627,40 @@ struct orc_scene
     h.albedo = V3{0.0f, 1.0f, 0.0f};
     h.emissive = V3{0.0f, 0.0f, 0.0f};
     h.triId = tr.triId;
+    if (materialsOn)
+    {
+      // texture coordinates as CPUScene.cpp:217-219 forms them, from the winning record's own barycentrics
+      Counters scratch;
+      V3 rv;
+      flatTri(tr, ray, tmin, tmax, rv, scratch);
+      const rtflat_shade& sh = fShade[tr.triId];
+      const V2 t0 = {sh.uv[0][0], sh.uv[0][1]}, t1 = {sh.uv[1][0], sh.uv[1][1]}, t2 = {sh.uv[2][0], sh.uv[2][1]};
+      const float b3 = 1.0f - rv.y - rv.z;
+      h.texCoords = t0 * rv.y + t1 * rv.z + t2 * b3;
+      flatMaterial(fMaterials[sh.material], h.texCoords, h.albedo, h.emissive);
+    }
     return h;
+  }
+  // a flattened material record evaluated like MaterialData::evaluate
+  void flatMaterial(const rtflat_material& m, V2 texCoords, V3& albedo, V3& emissive) const
+  {
+    auto sample = [&](uint32_t first, uint32_t w, uint32_t h) {
+      const uint32_t x = TextureData::texel(texCoords.x, (int)w), y = TextureData::texel(texCoords.y, (int)h);
+      const float* t = fTexels + 3 * ((size_t)first + (size_t)y * w + x);
+      return V3{t[0], t[1], t[2]};
+    };
+    if (m.kind == RTFLAT_MAT_STUB)
+    {
+      albedo = V3{texCoords.x, texCoords.y, 0.0f};
+      emissive = V3{0.0f, 0.0f, 0.0f};
+      return;
+    }
+    albedo = V3{m.baseColor[0], m.baseColor[1], m.baseColor[2]};
+    emissive = V3{m.emissive[0], m.emissive[1], m.emissive[2]};
+    if (m.albedoW)
+      albedo = albedo * sample(m.albedoTexel, m.albedoW, m.albedoH);
+    if (m.emissiveW)
+      emissive = emissive * sample(m.emissiveTexel, m.emissiveW, m.emissiveH);
   }
   bool any(bool flat, const RayO& ray, float tmin, float tmax, Counters& cnt) const
   {
@@ -637,9 +727,24 @@ struct orc_scene
       }
       if (path.depth < aovDepths)
         aovShadow[path.depth * aovStride] = mask;
-      for (const PtLight& pl : pointLights) // :39-49 (no shadow ray: commented out at :42)
+      for (size_t l = 0; l < pointLights.size(); ++l) // :39-49 (no shadow ray: commented out at :42)
       {
+        const PtLight& pl = pointLights[l];
         const V3 lightDir = pl.position - info.position;
+        if (pointShadows)
+        {
+          // Compute.metal:240-246: origin = position + normal * 1e-3, direction = lightDir (not normalised),
+          // max_distance = 1 (the light itself), min_distance left at 0; lit only when nothing is hit.
+          // (There `normal` is the interpolated vertex normal; this path has the face normal, CPUScene.cpp:239.)
+          cnt.shadow++;
+          if (any(flat, RayO{info.position + info.normal * 1e-3f, lightDir}, 0.0f, 1.0f, cnt))
+          {
+            const size_t bit = directionalLights.size() + l;
+            if (bit < 8 && path.depth < aovDepths)
+              aovShadow[path.depth * aovStride] |= (uint8_t)(1u << bit);
+            continue;
+          }
+        }
         const float dist = length(lightDir);
         const float illuminance = fmax_ref(1 - dist / pl.attenuation, 0.0f);
         path.radiance = path.radiance + illuminance * brdfEvaluate(info, -ray.direction, lightDir, pl.color);
@@ -801,6 +906,39 @@ void orc_add_model(orc_scene* s, const float* positions, uint32_t nPos, const fl
   std::memcpy(&t, transform, sizeof(t));
   orc_scene::transformModel(*m, t); // Scene.cpp:3-7
   s->models.push_back(std::move(m));
+}
+void orc_set_model_material(orc_scene* s, uint32_t modelIndex, uint32_t kind, const float baseColor[3], const float emissive[3],
+                            const float* albedoTexels, uint32_t albedoW, uint32_t albedoH, const float* emissiveTexels, uint32_t emissiveW,
+                            uint32_t emissiveH)
+{
+  if (modelIndex >= s->models.size())
+    return;
+  auto texture = [](const float* rgb, uint32_t w, uint32_t h) -> std::shared_ptr<TextureData> {
+    if (!rgb || !w || !h)
+      return nullptr;
+    auto t = std::make_shared<TextureData>();
+    t->width = (int)w, t->height = (int)h;
+    for (size_t k = 0; k < (size_t)w * h; ++k)
+      t->textureData.push_back(V3{rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2]});
+    return t;
+  };
+  MaterialData& m = s->models[modelIndex]->material;
+  m.kind = kind;
+  m.baseColor = V3{baseColor[0], baseColor[1], baseColor[2]};
+  m.emissiveFactor = V3{emissive[0], emissive[1], emissive[2]};
+  m.albedoTexture = texture(albedoTexels, albedoW, albedoH);
+  m.emissiveTexture = texture(emissiveTexels, emissiveW, emissiveH);
+}
+void orc_set_shading(orc_scene* s, int materialsOn, int pointShadows)
+{
+  s->materialsOn = materialsOn != 0;
+  s->pointShadows = pointShadows != 0;
+}
+void orc_set_flat_shading(orc_scene* s, const rtflat_shade* shade, const rtflat_material* materials, const float* texels)
+{
+  s->fShade = shade;
+  s->fMaterials = materials;
+  s->fTexels = texels;
 }
 void orc_generate(orc_scene* s) { s->generate(); }
 

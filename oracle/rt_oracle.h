@@ -67,6 +67,19 @@ void orc_add_point_light(orc_scene*, const float pos[3], const float color[3], f
  * accumulation (ModelLoader.cpp:18-39) then Scene::addModel -> Model::transform. */
 void orc_add_model(orc_scene*, const float* positions, uint32_t nPos, const float* texcoords, const uint32_t* indices,
                    uint32_t nTris, const float transform[16]);
+/* Shading beyond the reference's CPU path.  A model's material (src/util/Material.h:7-14): kind 0 =
+ * Material::evaluate as it stands (src/util/Material.cpp:4-12: albedo = (u, v, 0)), kind 1 = factor [* texture sample]
+ * (src/util/Texture.cpp:3-8) for albedo and emissive; textures are w*h RGB float triples or NULL.  Call after
+ * orc_add_model, any time before rendering. */
+void orc_set_model_material(orc_scene*, uint32_t modelIndex, uint32_t kind, const float baseColor[3], const float emissive[3],
+                            const float* albedoTexels, uint32_t albedoW, uint32_t albedoH, const float* emissiveTexels,
+                            uint32_t emissiveW, uint32_t emissiveH);
+/* materialsOn: hits take albedo / emissive from their model's material instead of the constants of
+ * src/cpu/CPUScene.cpp:243-247; pointShadows: point lights cast shadow rays as in src/metal/Compute.metal:238-254.
+ * Both 0 (the default) = the reference's CPU path as it stands. */
+void orc_set_shading(orc_scene*, int materialsOn, int pointShadows);
+/* variant B's view of the materials: the flattened shading tables (include/rtflat.h), owned by the caller */
+void orc_set_flat_shading(orc_scene*, const rtflat_shade* shade, const rtflat_material* materials, const float* texels);
 void orc_generate(orc_scene*);
 
 /* pool read-back for cross-checking the product's own Scene::generate / flattener */

@@ -57,6 +57,13 @@ MODEL_NODE_DTYPE = np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("left", "<u4")
 TRI_DTYPE = np.dtype([("p0", "<f4", 3), ("e0", "<f4", 3), ("e1", "<f4", 3), ("n", "<f4", 3), ("triId", "<u4"), ("orderKey", "<u4"),
                       ("pad", "<u4", 2)])
 assert NODE_DTYPE.itemsize == 64 and MODEL_NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 64
+# the shading tables of include/rtflat.h (scene option "materials")
+SHADE_DTYPE = np.dtype([("uv", "<f4", (3, 2)), ("material", "<u4"), ("pad", "<u4")])
+MATERIAL_DTYPE = np.dtype([("baseColor", "<f4", 3), ("kind", "<u4"), ("emissive", "<f4", 3), ("pad0", "<u4"),
+                           ("albedoTexel", "<u4"), ("albedoW", "<u4"), ("albedoH", "<u4"), ("pad1", "<u4"),
+                           ("emissiveTexel", "<u4"), ("emissiveW", "<u4"), ("emissiveH", "<u4"), ("pad2", "<u4")])
+assert SHADE_DTYPE.itemsize == 32 and MATERIAL_DTYPE.itemsize == 64
+MAT_STUB, MAT_FACTORS = 0, 1
 
 _host = None
 _hip = None
@@ -99,6 +106,8 @@ def hip_lib():
         L.rthip_synchronize.argtypes = [vp]
         L.rthip_get_counters.argtypes = [vp, C.POINTER(Counters)]
         L.rthip_get_kernel_times.argtypes = [vp, fp, up]
+        L.rthip_upload_materials.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64]
+        L.rthip_set_point_shadows.argtypes = [vp, C.c_int]
         _hip = L
     return _hip
 
@@ -124,6 +133,10 @@ def host_lib():
         L.rt_mesh_num_triangles.restype = C.c_uint32
         L.rt_mesh_num_triangles.argtypes = [vp]
         L.rt_mesh_copy.argtypes = [vp, fp, up]
+        L.rt_mesh_copy_texcoords.argtypes = [vp, fp]
+        L.rt_mesh_set_material.argtypes = [vp, C.c_uint32, fp, fp, fp, C.c_uint32, C.c_uint32, fp, C.c_uint32, C.c_uint32]
+        L.rt_mesh_get_material.argtypes = [vp, up, fp, fp]
+        L.rt_get_flat_shading.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), up, C.POINTER(vp), C.POINTER(C.c_uint64)]
         L.rt_mesh_destroy.argtypes = [vp]
         L.rt_renderer_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
         L.rt_renderer_destroy.argtypes = [vp]
@@ -187,6 +200,7 @@ class Mesh:
         if not handle:
             raise RtError(RTHIP_E_ARG, "mesh creation")
         self._h = handle
+        self.material_spec = None  # the arguments of the last set_material (so a second consumer can be given the same)
 
     @classmethod
     def cube(cls):
@@ -215,10 +229,42 @@ class Mesh:
         return [cls(h) for h in arr]
 
     @classmethod
-    def from_arrays(cls, positions, indices):
+    def from_arrays(cls, positions, indices, texcoords=None):
         p = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
         i = np.ascontiguousarray(indices, np.uint32).reshape(-1, 3)
-        return cls(host_lib().rt_mesh_from_arrays(_fp(p), p.shape[0], None, _up(i), i.shape[0]))
+        tc = None
+        if texcoords is not None:
+            t = np.ascontiguousarray(texcoords, np.float32).reshape(-1, 2)
+            assert t.shape[0] == p.shape[0]
+            tc = _fp(t)
+        return cls(host_lib().rt_mesh_from_arrays(_fp(p), p.shape[0], tc, _up(i), i.shape[0]))
+
+    def set_material(self, kind=MAT_FACTORS, base_color=(0, 1, 0), emissive=(0, 0, 0), albedo_texture=None, emissive_texture=None):
+        """The mesh's Material (src/util/Material.h:7-14); textures are float32 arrays [h, w, 3] or None.  Read by the path
+        only when the scene option "materials" is set."""
+        def tex(t):
+            if t is None:
+                return None, 0, 0
+            a = np.ascontiguousarray(t, np.float32)
+            assert a.ndim == 3 and a.shape[2] == 3
+            return _fp(a), a.shape[1], a.shape[0]
+        b, e = np.asarray(base_color, np.float32), np.asarray(emissive, np.float32)
+        ap, aw, ah = tex(albedo_texture)
+        ep, ew, eh = tex(emissive_texture)
+        _check(host_lib().rt_mesh_set_material(self._h, int(kind), _fp(b), _fp(e), ap, aw, ah, ep, ew, eh), "rt_mesh_set_material")
+        self.material_spec = dict(kind=int(kind), base_color=b.copy(), emissive=e.copy(), albedo_texture=albedo_texture, emissive_texture=emissive_texture)
+
+    def material(self):
+        """(kind, base colour, emissive) -- for a loaded .glb mesh its primitive's glTF factors"""
+        k = C.c_uint32()
+        b, e = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        _check(host_lib().rt_mesh_get_material(self._h, C.byref(k), _fp(b), _fp(e)), "rt_mesh_get_material")
+        return int(k.value), b, e
+
+    def texcoords(self):
+        t = np.zeros((self.num_positions, 2), np.float32)
+        host_lib().rt_mesh_copy_texcoords(self._h, _fp(t))
+        return t
 
     @property
     def num_positions(self):
@@ -377,6 +423,23 @@ class Renderer:
         return dict(_owner=self, info=i, info_bytes=bytes(C.string_at(C.addressof(i), C.sizeof(FlatInfo))),
                     model_nodes=view(mn, i.numModelNodes, MODEL_NODE_DTYPE), nodes=view(nd, max(i.numNodes, 1), NODE_DTYPE),
                     tris=view(tr, max(i.numTris, 1), TRI_DTYPE), build_seconds=secs.value)
+
+    def flat_shading(self):
+        """Views (no copy) of the shading tables handed to the device: shade[numTris], materials[numModels], texels[n, 3];
+        None unless the scene option "materials" was set."""
+        sh, mt, tx = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nm, nt = C.c_uint32(), C.c_uint64()
+        _check(host_lib().rt_get_flat_shading(self._h, C.byref(sh), C.byref(mt), C.byref(nm), C.byref(tx), C.byref(nt)), "rt_get_flat_shading")
+        if not sh.value:
+            return None
+        n_tris = self.flat()["info"].numTris
+
+        def view(ptr, count, dtype):
+            buf = (C.c_char * (dtype.itemsize * count)).from_address(ptr.value)
+            return np.frombuffer(buf, dtype=dtype, count=count)
+
+        texels = view(tx, 3 * nt.value, np.dtype("<f4")).reshape(-1, 3) if tx.value else np.zeros((0, 3), np.float32)
+        return dict(_owner=self, shade=view(sh, n_tris, SHADE_DTYPE), materials=view(mt, nm.value, MATERIAL_DTYPE), texels=texels)
 
     def build_times(self):
         """(host seconds of the flattener, device milliseconds of the BVH build -- 0 unless option deviceBvh was set)"""

@@ -191,6 +191,55 @@ RTD int triangleTest(vec3 p0, vec3 e0, vec3 e1, vec3 o, vec3 d, float tmin, floa
   return 1;
 }
 
+// ---- materials (include/rtflat.h: rtflat_shade / rtflat_material)
+// The texture coordinates the reference's intersector attaches to a hit (CPUScene.cpp:217-219): the triangle test's own
+// barycentrics, recomputed here for the winning record from the same operands in the same order, so the same bits.
+RTD void hitTexCoords(vec3 p0, vec3 e0, vec3 e1, vec3 o, vec3 d, const float uv[3][2], float& u, float& v)
+{
+  const vec3 s = o - p0;
+  const vec3 s1 = rt::cross(d, e1);
+  const vec3 s2 = rt::cross(s, e0);
+  const float fraction = 1.0f / rt::dot(s1, e0);
+  const float b1 = rt::dot(s1, s) * fraction;
+  const float b2 = rt::dot(s2, d) * fraction;
+  const float b3 = 1.0f - b1 - b2;
+  u = uv[0][0] * b1 + uv[1][0] * b2 + uv[2][0] * b3; // t0 * y + t1 * z + t2 * b3 (:219)
+  v = uv[0][1] * b1 + uv[1][1] * b2 + uv[2][1] * b3;
+}
+// src/util/Texture.cpp:5-6: texel column / row = uint32(coordinate * size).  The reference converts unchecked and reads out
+// of bounds for coordinates outside [0,1); here those clamp to the edge texels (NaN -> 0), the same on host and device.
+RTD uint32_t texelIndex(float coord, uint32_t size)
+{
+  const float f = coord * (float)size;
+  if (!(f >= 0.0f))
+    return 0u;
+  if (f >= (float)size)
+    return size - 1u;
+  return (uint32_t)f;
+}
+RTD vec3 textureSample(const float* texels, uint32_t first, uint32_t w, uint32_t h, float u, float v)
+{
+  const uint32_t x = texelIndex(u, w), y = texelIndex(v, h);
+  const float* t = texels + 3 * ((size_t)first + (size_t)y * w + x); // textureData[y * width + x] (Texture.cpp:7)
+  return vec3{t[0], t[1], t[2]};
+}
+// what src/util/Material.cpp:4-12 stands for: the BRDF inputs of a hit from its material and texture coordinates
+RTD void materialEvaluate(const rtflat_material& m, const float* texels, float u, float v, vec3& albedo, vec3& emissive)
+{
+  if (m.kind == RTFLAT_MAT_STUB) // the reference's body as it stands
+  {
+    albedo = vec3{u, v, 0.0f};
+    emissive = vec3{0.0f, 0.0f, 0.0f};
+    return;
+  }
+  albedo = vec3{m.baseColor[0], m.baseColor[1], m.baseColor[2]};
+  emissive = vec3{m.emissive[0], m.emissive[1], m.emissive[2]};
+  if (m.albedoW)
+    albedo = albedo * textureSample(texels, m.albedoTexel, m.albedoW, m.albedoH, u, v);
+  if (m.emissiveW)
+    emissive = emissive * textureSample(texels, m.emissiveTexel, m.emissiveW, m.emissiveH, u, v);
+}
+
 // 1/d for the padded-box tests, clamped to +-1e18 so that an exactly axis-parallel ray (d == 0 -> 1/d == inf) keeps
 // finite slab arithmetic (inf - inf would turn into a NaN that fminf/fmaxf silently drop)
 RTD vec3 padInvDir(vec3 d)

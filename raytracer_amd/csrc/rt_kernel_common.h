@@ -37,9 +37,11 @@ enum TraceMode
   SHADOW = 1,   // any-hit toward every directional light from the stored origin
   ANYPROBE = 2, // any-hit of the stored ray (probe entry point)
   PRIMARY = 3,  // ray generation fused in (the primary ray is computed in registers, never stored); dynamic work fetch
-  PRIMARY_GROUP = 4 // the same for tiny scenes: static runs, one 8x8 pixel block at a time, no refilling
+  PRIMARY_GROUP = 4, // the same for tiny scenes: static runs, one 8x8 pixel block at a time, no refilling
+  SHADOW_PT = 5  // SHADOW, then any-hit toward every point light as well (Compute.metal:238-254): per-lane origin and t range
 };
 constexpr bool isPrimary(int mode) { return mode == PRIMARY || mode == PRIMARY_GROUP; }
+constexpr bool isShadow(int mode) { return mode == SHADOW || mode == SHADOW_PT; }
 constexpr bool isClosest(int mode) { return mode == CLOSEST || isPrimary(mode); }
 
 struct DeviceScene
@@ -49,6 +51,12 @@ struct DeviceScene
   const rtflat_tri* tris;
   uint32_t numModelNodes;
   float cullRel, cullAbs;
+  // shading inputs (rthip_upload_materials); materialsOn == 0: the reference's hard-coded albedo
+  const rtflat_shade* shade;
+  const rtflat_material* materials;
+  const float* texels;
+  uint32_t materialsOn;
+  uint32_t pointShadows; // point lights are shadowed: their occlusion bits follow the directional lights' in mask[]
 };
 
 struct Lights
@@ -96,6 +104,7 @@ struct PathBuffers
   float* nz;     // face normal z of the previous hit
   uint8_t* live; // depth at which the path is waiting, kDead / kDeadZero when finished
   uint8_t* mask; // occlusion bits of the previous hit's shadow rays
+  float4* alb;   // albedo of the previous hit (materials only; without them it is the constant of CPUScene.cpp:245)
 };
 
 __device__ __forceinline__ uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -148,12 +157,14 @@ __device__ __forceinline__ bool pixelOf(const FrameGeom& g, uint32_t i, uint32_t
   return w < g.width && h < g.height;
 }
 
+__device__ __forceinline__ vec3 referenceAlbedo() { return vec3{0.0f, 1.0f, 0.0f}; } // CPUScene.cpp:245
+
 // Adds the direct light of the hit a path has just left (CPUScene.cpp:31-49, lights in that order): directional lights
-// unless their shadow ray was occluded, then the point lights, unshadowed.  `o` is the hit position, nPrev its face normal.
-// One function for k_shade and the shadow kernel's final fold, so both produce the same bits.
-__device__ __forceinline__ vec3 foldLights(const Lights* lights, uint32_t occluded, vec3 o, vec3 nPrev, vec3 radiance)
+// unless their shadow ray was occluded, then the point lights -- unshadowed as on the reference's CPU path, or, with
+// pointShadows, skipped when their bit (after the directional lights') is set.  `o` is the hit position, nPrev its face
+// normal, albedo the hit's.  One function for k_shade and the shadow kernel's final fold, so both produce the same bits.
+__device__ __forceinline__ vec3 foldLights(const Lights* lights, uint32_t occluded, vec3 o, vec3 nPrev, vec3 radiance, vec3 albedo, uint32_t pointShadows)
 {
-  const vec3 albedo{0.0f, 1.0f, 0.0f}; // CPUScene.cpp:245
   for (uint32_t l = 0; l < lights->numDir; ++l)
   {
     const rthip_dir_light& L = lights->dir[l];
@@ -164,6 +175,8 @@ __device__ __forceinline__ vec3 foldLights(const Lights* lights, uint32_t occlud
   for (uint32_t l = 0; l < lights->numPoint; ++l)
   {
     const rthip_point_light& L = lights->point[l];
+    if (pointShadows && ((occluded >> (lights->numDir + l)) & 1u))
+      continue;
     const vec3 lightDir = vec3{L.position[0], L.position[1], L.position[2]} - o;
     const float dist = rt::length(lightDir);
     const float illuminance = rt::maxRef(1 - dist / L.attenuation, 0.0f);

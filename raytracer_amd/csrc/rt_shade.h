@@ -64,15 +64,15 @@ struct ShadeArgs
 // run of kShadeRun consecutive items, keeps the surviving slots in LDS in item order, and publishes them with ONE atomic,
 // so the list keeps the spatial order of the slots (neighbouring entries = neighbouring pixels and samples) and the one
 // counter word sees numItems / 1024 atomics per launch instead of one per wave iteration.
-template <bool SPARSE>
+// MAT: the scene carries materials (rthip_upload_materials): a hit's albedo / emissive come from its model's material at the
+// hit's texture coordinates and the albedo travels with the path (pb.alb) to the light fold one depth later.
+template <bool SPARSE, bool MAT>
 __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
 {
   __shared__ uint32_t sKeep[kWavesPerBlock][kShadeRun];
   __shared__ uint32_t sAlive[kWavesPerBlock], sHits[kWavesPerBlock];
   uint32_t nAlive = 0, nHits = 0;
   const uint8_t depthTag = (uint8_t)a.depth;
-  const vec3 albedo{0.0f, 1.0f, 0.0f};    // CPUScene.cpp:245
-  const vec3 emissive{0.0f, 0.0f, 0.0f};  // CPUScene.cpp:246
   const uint32_t total = SPARSE ? a.counters->listCount[a.depth] : a.numSlots;
   const uint32_t lane = laneId(), wv = threadIdx.x >> 6;
   uint32_t* keep = sKeep[wv];
@@ -126,8 +126,15 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
             material.y = s1.x, material.z = s1.y;
           }
           // lights of the previous hit, whose position is this ray's origin (CPUScene.cpp:31-49)
-          const uint32_t occl = a.lights->numDir ? a.pb.mask[p] : 0u;
-          radiance = foldLights(a.lights, occl, o, vec3{ro.w, s0.w, a.pb.nz[p]}, radiance);
+          const bool shadowed = a.lights->numDir || (a.scene.pointShadows && a.lights->numPoint);
+          const uint32_t occl = shadowed ? a.pb.mask[p] : 0u;
+          vec3 albedoPrev = referenceAlbedo();
+          if (MAT)
+          {
+            const float4 al = a.pb.alb[p];
+            albedoPrev = vec3{al.x, al.y, al.z};
+          }
+          radiance = foldLights(a.lights, occl, o, vec3{ro.w, s0.w, a.pb.nz[p]}, radiance, albedoPrev, a.scene.pointShadows);
           if (a.depth - 1 < a.aovDepths)
             a.aovShadow[((size_t)s * a.aovDepths + (a.depth - 1)) * a.g.numLocalPixels + i] = (uint8_t)occl;
         }
@@ -135,6 +142,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
       bool finished = folding;
       uint32_t rec = RTFLAT_INVALID;
       float t = FLT_MAX;
+      vec3 albedo = referenceAlbedo();        // CPUScene.cpp:245
+      vec3 emissive{0.0f, 0.0f, 0.0f};        // CPUScene.cpp:246
+      float4 a2 = make_float4(0, 0, 0, 0), a3 = a2; // third and fourth quarter of the hit's triangle record
       if (!finished)
       {
         const uint2 hv = a.pb.hit[p];
@@ -149,6 +159,17 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
           rnd = rtd::rand01(w, h, a.sampBegin + s);
           if (regen) // the primary ray was never stored: same function, same bits (only paths that hit need it)
             rtd::primaryRay(*a.cam, a.g.width, a.g.height, w, h, a.sampBegin + s, rnd, o, d);
+          const float4* tp = reinterpret_cast<const float4*>(a.scene.tris + rec);
+          a2 = tp[2], a3 = tp[3];
+          if (MAT)
+          {
+            // IntersectionInfo::brdf of this hit (CPUScene.cpp:232-247 with the material in place of the constants)
+            const float4 a0 = tp[0], a1 = tp[1];
+            const rtflat_shade sh = a.scene.shade[__float_as_uint(a3.x)];
+            float u, v;
+            rtd::hitTexCoords(vec3{a0.x, a0.y, a0.z}, vec3{a0.w, a1.x, a1.y}, vec3{a1.z, a1.w, a2.x}, o, d, sh.uv, u, v);
+            rtd::materialEvaluate(a.scene.materials[sh.material], a.scene.texels, u, v, albedo, emissive);
+          }
           const float pr = rt::maxRef(rt::maxRef(albedo.x, albedo.y), albedo.z); // :13
           if (a.depth > 5)                                                      // :19 (depth >= maxDepth never reaches here)
           {
@@ -171,8 +192,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
       }
       else
       {
-        const float4* tp = reinterpret_cast<const float4*>(a.scene.tris + rec);
-        const float4 a2 = tp[2], a3 = tp[3];
         const vec3 n{a2.y, a2.z, a2.w};
         if (a.depth < a.aovDepths)
           a.aovTri[((size_t)s * a.aovDepths + a.depth) * a.g.numLocalPixels + i] = __float_as_uint(a3.x);
@@ -183,6 +202,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
         a.pb.rayO[p] = make_float4(position.x, position.y, position.z, n.x);
         a.pb.s0[p] = make_float4(radiance.x, radiance.y, radiance.z, n.y);
         a.pb.nz[p] = n.z;
+        if (MAT)
+          a.pb.alb[p] = make_float4(albedo.x, albedo.y, albedo.z, 0.0f);
         if (a.depth + 1 < a.maxDepth) // the last shaded depth traces no bounce ray: neither direction nor throughput is kept
         {
           const vec3 normalLight = rt::dot(n, d) < 0 ? n : -n;                    // :240

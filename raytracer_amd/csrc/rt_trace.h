@@ -34,7 +34,7 @@ struct TraceArgs
 };
 
 template <int MODE, bool COUNT>
-__global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs a)
+__global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 6)) void k_trace(TraceArgs a)
 {
   __shared__ uint32_t sStack[kWavesPerBlock][kStackLds][64];
   __shared__ uint32_t sList[kWavesPerBlock][kChunk];
@@ -110,19 +110,53 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
   uint32_t sp = 0, spLo = 0;     // stack entries [spLo, sp) are in LDS, [0, spLo) spilled
   uint32_t postponed = 0xfffffffeu; // a leaf reference parked while the lane keeps walking inner nodes (kNone = none)
   bool needPop = false;          // the lane needs a new `cur` from its stack / the model tree
-  uint32_t lightIdx = 0;         // SHADOW: which directional light this lane is testing
+  uint32_t lightIdx = 0;         // SHADOW: which light this lane is testing (directional lights first, then -- SHADOW_PT -- point lights)
   uint32_t occluded = 0;         // SHADOW: result bits
   float prevNx = 0.0f;           // SHADOW: rayO.w, the face normal x of the hit the shadow rays leave from
+  vec3 hitPos{0, 0, 0}, hitN{0, 0, 0}; // SHADOW_PT: that hit's position and face normal (a point light's ray starts off the surface)
+  float tmn = a.tmin, tmx = a.tmax;    // SHADOW_PT: per-lane t range (the launch's for directional lights, [0,1] for point lights)
+  const uint32_t numShadowLights = isShadow(MODE) ? a.lights->numDir + (MODE == SHADOW_PT ? a.lights->numPoint : 0u) : 0u;
   uint32_t nRays = 0, nNodes = 0, nTris = 0, nNodeSteps = 0, nLeafSteps = 0;
 
   // SHADOW: every light of this lane's path has been tested.  Normally the occlusion bits go to mask[] and the next
   // shade launch folds the lights; at the last depth the fold happens right here (same function, same bits), which
   // saves that launch and its re-read of the path state.
+  // points the lane's ray at light l from the hit it is testing
+  auto aimAtLight = [&](uint32_t l) {
+    if (MODE == SHADOW_PT && l >= a.lights->numDir)
+    {
+      const rthip_point_light& L = a.lights->point[l - a.lights->numDir];
+      d = vec3{L.position[0], L.position[1], L.position[2]} - hitPos; // Compute.metal:240,243: not normalised, the light is at t = 1
+      o = hitPos + hitN * 1e-3f;                                      // :242
+      tmn = 0.0f, tmx = 1.0f;                                         // :244 (min_distance defaults to 0)
+      cull = rt::fma(tmx, 1.0f + a.scene.cullRel, a.scene.cullAbs);   // boxes beyond the light cannot hold an accepted triangle
+    }
+    else
+    {
+      const rthip_dir_light& L = a.lights->dir[l];
+      d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]}; // Ray(position, -d.direction), CPUScene.cpp:34
+      if (MODE == SHADOW_PT)
+      {
+        o = hitPos;
+        tmn = a.tmin, tmx = a.tmax;
+        cull = FLT_MAX;
+      }
+    }
+    invD = rtd::padInvDir(d);
+    oi = o * invD;
+  };
   auto finishShadow = [&]() {
     if (a.foldFinal)
     {
       const float4 s0 = a.pb.s0[slot];
-      const vec3 radiance = foldLights(a.lights, occluded, o, vec3{prevNx, s0.w, a.pb.nz[slot]}, vec3{s0.x, s0.y, s0.z});
+      const vec3 from = MODE == SHADOW_PT ? hitPos : o;
+      vec3 albedo = referenceAlbedo();
+      if (a.scene.materialsOn)
+      {
+        const float4 al = a.pb.alb[slot];
+        albedo = vec3{al.x, al.y, al.z};
+      }
+      const vec3 radiance = foldLights(a.lights, occluded, from, vec3{prevNx, s0.w, a.pb.nz[slot]}, vec3{s0.x, s0.y, s0.z}, albedo, a.scene.pointShadows);
       if (a.depth - 1 < a.aovDepths)
       {
         uint32_t sidx, i;
@@ -277,23 +311,27 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
           slot = list[listNext + r];
           const float4 ro = a.pb.rayO[slot];
           o = vec3{ro.x, ro.y, ro.z};
-          if (MODE == SHADOW)
+          best = FLT_MAX;
+          cull = FLT_MAX;
+          if (isShadow(MODE))
           {
             lightIdx = 0;
             occluded = 0;
             prevNx = ro.w;
-            const rthip_dir_light& L = a.lights->dir[0];
-            d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]}; // Ray(position, -d.direction), CPUScene.cpp:34
+            if (MODE == SHADOW_PT)
+            {
+              hitPos = o;
+              hitN = vec3{ro.w, a.pb.s0[slot].w, a.pb.nz[slot]};
+            }
+            aimAtLight(0);
           }
           else
           {
             const float4 rd = a.pb.rayD[slot];
             d = vec3{rd.x, rd.y, rd.z};
+            invD = rtd::padInvDir(d);
+            oi = o * invD;
           }
-          invD = rtd::padInvDir(d);
-          oi = o * invD;
-          best = FLT_MAX;
-          cull = FLT_MAX;
           bestRec = RTFLAT_INVALID;
           cur = kNone;
           postponed = kNone;
@@ -354,7 +392,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
             vec3 invRef = invD;
             if (fabsf(invD.x) == 1e18f || fabsf(invD.y) == 1e18f || fabsf(invD.z) == 1e18f)
               invRef = rt::rcp3(d);
-            if (!rtd::refSlab(mn->lo, mn->hi, o, invRef, a.tmin, a.tmax))
+            if (!rtd::refSlab(mn->lo, mn->hi, o, invRef, MODE == SHADOW_PT ? tmn : a.tmin, MODE == SHADOW_PT ? tmx : a.tmax))
             {
               mk += mn->subtreeSize; // skip the subtree
               continue;
@@ -379,16 +417,13 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
       if (active && cur == kDone && postponed == kNone)
       {
         bool done = true;
-        if (MODE == SHADOW)
+        if (isShadow(MODE))
         {
           // not occluded for this light; the next light restarts the walk
           lightIdx++;
-          if (lightIdx < a.lights->numDir)
+          if (lightIdx < numShadowLights)
           {
-            const rthip_dir_light& L = a.lights->dir[lightIdx];
-            d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]};
-            invD = rtd::padInvDir(d);
-            oi = o * invD;
+            aimAtLight(lightIdx);
             mk = 0;
             needPop = true;
             cur = kNone;
@@ -441,7 +476,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
             if (COUNT)
               nTris++;
             float t;
-            const int acc = rtd::triangleTest(vec3{a0.x, a0.y, a0.z}, vec3{a0.w, a1.x, a1.y}, vec3{a1.z, a1.w, a2.x}, o, d, a.tmin, a.tmax, t);
+            const int acc = rtd::triangleTest(vec3{a0.x, a0.y, a0.z}, vec3{a0.w, a1.x, a1.y}, vec3{a1.z, a1.w, a2.x}, o, d, MODE == SHADOW_PT ? tmn : a.tmin,
+                                              MODE == SHADOW_PT ? tmx : a.tmax, t);
             if (acc == 2)
               atomicAdd(&a.counters->nonFinite, 1ull);
             if (acc != 1)
@@ -471,16 +507,13 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
           if (!isClosest(MODE) && anyAccepted)
           {
             // first accepted triangle ends an any-hit ray (testModel returns true, CPUScene.cpp:182)
-            if (MODE == SHADOW)
+            if (isShadow(MODE))
             {
               occluded |= 1u << lightIdx;
               lightIdx++;
-              if (lightIdx < a.lights->numDir)
+              if (lightIdx < numShadowLights)
               {
-                const rthip_dir_light& L = a.lights->dir[lightIdx];
-                d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]};
-                invD = rtd::padInvDir(d);
-                oi = o * invD;
+                aimAtLight(lightIdx);
                 mk = 0;
                 sp = spLo = 0;
                 cur = kNone;
@@ -527,7 +560,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
         float en0, ex0, en1, ex1, en2, ex2, en3, ex3;
         rtd::wideSlabPair<0>(wn, en0, ex0, en1, ex1);
         rtd::wideSlabPair<2>(wn, en2, ex2, en3, ex3);
-        constexpr bool kClosest = isClosest(MODE);
+        constexpr bool kClosest = isClosest(MODE) || MODE == SHADOW_PT; // modes whose rays have a far limit worth culling against
         // sort the (at most four) children that were hit by entry distance; unused slots have inverted boxes
         uint32_t k0 = ((en0 <= ex0) && (!kClosest || en0 <= cull)) ? __float_as_uint(en0) : 0xffffffffu;
         uint32_t k1 = ((en1 <= ex1) && (!kClosest || en1 <= cull)) ? __float_as_uint(en1) : 0xffffffffu;
@@ -587,7 +620,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 4 ? 5 : 6)) void k_trace(TraceArgs
     if (nRays)
     {
       unsigned long long* dst =
-          (MODE == SHADOW) ? &a.counters->shadow : ((isPrimary(MODE) || a.depth == 0) ? &a.counters->extendPrimary : &a.counters->extendSecondary);
+          isShadow(MODE) ? &a.counters->shadow : ((isPrimary(MODE) || a.depth == 0) ? &a.counters->extendPrimary : &a.counters->extendSecondary);
       atomicAdd(dst, (unsigned long long)nRays);
     }
     if (COUNT)

@@ -160,6 +160,12 @@ struct rthip_ctx
   DevBuf<rtflat_tri> tris;
   DevBuf<Lights> lights;
   Lights hostLights{};
+  // shading inputs (rthip_upload_materials): per-triangle texture coordinates + material index, materials, texel pool
+  DevBuf<rtflat_shade> shade;
+  DevBuf<rtflat_material> materials;
+  DevBuf<float> texels;
+  bool materialsOn = false;
+  bool pointShadows = false; // rthip_set_point_shadows
   // frame
   bool haveFrame = false;
   rthip_camera camera{};
@@ -170,7 +176,7 @@ struct rthip_ctx
   std::vector<uint32_t> hostTileIds, hostTileXY;
   DevBuf<uint32_t> tileIds;
   DevBuf<CameraConsts> camConsts;
-  DevBuf<float4> rayO, rayD, s0;
+  DevBuf<float4> rayO, rayD, s0, alb;
   DevBuf<float2> s1;
   DevBuf<float> nz;
   DevBuf<uint2> hit;
@@ -206,7 +212,7 @@ struct rthip_ctx
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr, evDone = nullptr;
     uint32_t fetchCursor = 0;
-    DevBuf<float4> rayO, rayD, s0;
+    DevBuf<float4> rayO, rayD, s0, alb;
     DevBuf<float2> s1;
     DevBuf<float> nz;
     DevBuf<uint2> hit;
@@ -298,6 +304,11 @@ DeviceScene devScene(const rthip_ctx* c)
   s.numModelNodes = c->info.numModelNodes;
   s.cullRel = c->info.cullRel;
   s.cullAbs = c->info.cullAbs;
+  s.shade = c->shade.p;
+  s.materials = c->materials.p;
+  s.texels = c->texels.p;
+  s.materialsOn = c->materialsOn ? 1u : 0u;
+  s.pointShadows = (c->pointShadows && c->hostLights.numPoint) ? 1u : 0u;
   return s;
 }
 constexpr size_t kCounterWords = ((sizeof(DeviceCounters) + 255) / 256) * 64; // DeviceCounters rounded up to 256 B, in words
@@ -325,7 +336,7 @@ void swapSlot(rthip_ctx* c)
   std::swap(c->evFork, a.evFork), std::swap(c->evJoin, a.evJoin), std::swap(c->evDone, a.evDone);
   std::swap(c->fetchCursor, a.fetchCursor);
   std::swap(c->rayO, a.rayO), std::swap(c->rayD, a.rayD), std::swap(c->s0, a.s0), std::swap(c->s1, a.s1), std::swap(c->nz, a.nz);
-  std::swap(c->hit, a.hit), std::swap(c->live, a.live), std::swap(c->mask, a.mask);
+  std::swap(c->hit, a.hit), std::swap(c->live, a.live), std::swap(c->mask, a.mask), std::swap(c->alb, a.alb);
   std::swap(c->spill, a.spill), std::swap(c->spill2, a.spill2), std::swap(c->fetch, a.fetch);
   std::swap(c->listA, a.listA), std::swap(c->listB, a.listB);
 }
@@ -334,6 +345,7 @@ PathBuffers pathBuffers(const rthip_ctx* c)
 {
   PathBuffers pb;
   pb.rayO = c->rayO.p, pb.rayD = c->rayD.p, pb.hit = c->hit.p, pb.s0 = c->s0.p, pb.s1 = c->s1.p, pb.nz = c->nz.p, pb.live = c->live.p, pb.mask = c->mask.p;
+  pb.alb = c->alb.p;
   return pb;
 }
 
@@ -395,6 +407,8 @@ int ensurePathBuffers(rthip_ctx* c, size_t numSlots)
   int rc;
   if ((rc = c->rayO.ensure(numSlots)) || (rc = c->rayD.ensure(numSlots)) || (rc = c->s0.ensure(numSlots)) || (rc = c->s1.ensure(numSlots)) || (rc = c->nz.ensure(numSlots)) ||
       (rc = c->hit.ensure(numSlots)) || (rc = c->live.ensure(numSlots + 64)) || (rc = c->mask.ensure(numSlots)))
+    return rc;
+  if (c->materialsOn && (rc = c->alb.ensure(numSlots)))
     return rc;
   uint32_t blocks, runLen;
   staticGeometry((uint32_t)numSlots, blocks, runLen);
@@ -507,7 +521,9 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, uint32_t tileB
                        numSlots);
     HIPCHK(hipGetLastError());
   }
-  const bool haveDirLights = c->hostLights.numDir > 0;
+  // shadow rays: toward every directional light (CPUScene.cpp:31-38) and, when asked for, every point light
+  const bool shadowPoints = c->pointShadows && c->hostLights.numPoint > 0;
+  const bool haveDirLights = c->hostLights.numDir > 0 || shadowPoints;
   ShadeArgs sa;
   sa.g = g;
   sa.scene = devScene(c);
@@ -540,7 +556,9 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, uint32_t tileB
       HIPCHK(hipEventRecord(c->evFork, c->stream));
       HIPCHK(hipStreamWaitEvent(c->stream2, c->evFork, 0));
     }
-    if (d > 0 && haveDirLights && (rc = launchTrace<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g)))
+    if (d > 0 && haveDirLights &&
+        (rc = shadowPoints ? launchTrace<SHADOW_PT>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g)
+                           : launchTrace<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g)))
       return rc;
     if (side)
     {
@@ -569,10 +587,17 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, uint32_t tileB
     sa.listNext = last ? nullptr : listNext;
     {
       KernelTimer kt(c, 2);
-      if (d > 0)
-        hipLaunchKernelGGL(k_shade<true>, dim3(shadeBlocks), dim3(kBlock), 0, c->stream, sa);
+      if (c->materialsOn)
+      {
+        if (d > 0)
+          hipLaunchKernelGGL((k_shade<true, true>), dim3(shadeBlocks), dim3(kBlock), 0, c->stream, sa);
+        else
+          hipLaunchKernelGGL((k_shade<false, true>), dim3(shadeBlocks), dim3(kBlock), 0, c->stream, sa);
+      }
+      else if (d > 0)
+        hipLaunchKernelGGL((k_shade<true, false>), dim3(shadeBlocks), dim3(kBlock), 0, c->stream, sa);
       else
-        hipLaunchKernelGGL(k_shade<false>, dim3(shadeBlocks), dim3(kBlock), 0, c->stream, sa);
+        hipLaunchKernelGGL((k_shade<false, false>), dim3(shadeBlocks), dim3(kBlock), 0, c->stream, sa);
       HIPCHK(hipGetLastError());
     }
     if (last)
@@ -874,6 +899,7 @@ int rthip_upload_scene(rthip_ctx* c, const rtflat_info* info, const rtflat_model
   c->spillCap = 3 * deepest + 2 > kStackLds ? 3 * deepest + 2 - kStackLds : 1u;
   c->spill.release(); // sized per scene in ensurePathBuffers
   c->alt.spill.release();
+  c->materialsOn = false; // they described the previous scene's triangles
   c->haveScene = true;
   c->haveFrame = false;
   return 0;
@@ -909,6 +935,7 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
   HIPCHK(hipStreamSynchronize(c->stream));
   c->haveScene = false;
   c->haveFrame = false;
+  c->materialsOn = false;
   int rc;
   const uint32_t nodeCap = std::max(1u, numTris);
   DevBuf<rtflat_tri> trisIn;
@@ -1067,6 +1094,61 @@ int rthip_download_scene(rthip_ctx* c, rtflat_node* nodesOut, uint32_t nodeCapac
   return 0;
 }
 
+int rthip_upload_materials(rthip_ctx* c, const rtflat_shade* shade, uint32_t numTris, const rtflat_material* materials, uint32_t numMaterials,
+                           const float* texels, uint64_t numTexels)
+{
+  if (!c || !shade || !materials || numMaterials == 0 || (numTexels && !texels))
+    return RTHIP_E_ARG;
+  if (!c->haveScene)
+    return RTHIP_E_STATE;
+  if (numTris != c->info.numTris)
+    return RTHIP_E_ARG; // one record per triangle of the uploaded scene, indexed by triId
+  // everything the kernels index with is checked here, once: they do no bounds checks of their own
+  for (uint32_t m = 0; m < numMaterials; ++m)
+  {
+    const rtflat_material& mt = materials[m];
+    if (mt.kind != RTFLAT_MAT_STUB && mt.kind != RTFLAT_MAT_FACTORS)
+      return RTHIP_E_ARG;
+    auto inPool = [&](uint32_t first, uint32_t w, uint32_t h) {
+      if (w == 0)
+        return true;
+      return h != 0 && w <= (1u << 24) && h <= (1u << 24) && (uint64_t)first + (uint64_t)w * h <= numTexels;
+    };
+    if (!inPool(mt.albedoTexel, mt.albedoW, mt.albedoH) || !inPool(mt.emissiveTexel, mt.emissiveW, mt.emissiveH))
+      return RTHIP_E_ARG;
+  }
+  for (uint32_t k = 0; k < numTris; ++k)
+    if (shade[k].material >= numMaterials)
+      return RTHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->alt.stream)); // frames in flight shade with the old tables
+  HIPCHK(hipStreamSynchronize(c->alt.stream2));
+  HIPCHK(hipStreamSynchronize(c->stream2));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->altPending = false;
+  c->materialsOn = false;
+  int rc;
+  if ((rc = c->shade.ensure(numTris)) || (rc = c->materials.ensure(numMaterials)) || (rc = c->texels.ensure(std::max<uint64_t>(1, 3 * numTexels))))
+    return rc;
+  HIPCHK(hipMemcpy(c->shade.p, shade, sizeof(rtflat_shade) * numTris, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->materials.p, materials, sizeof(rtflat_material) * numMaterials, hipMemcpyHostToDevice));
+  if (numTexels)
+    HIPCHK(hipMemcpy(c->texels.p, texels, sizeof(float) * 3 * numTexels, hipMemcpyHostToDevice));
+  c->materialsOn = true;
+  c->haveFrame = false; // the next rthip_begin sizes the albedo array of the path state
+  return 0;
+}
+
+int rthip_set_point_shadows(rthip_ctx* c, int on)
+{
+  if (!c)
+    return RTHIP_E_ARG;
+  if (on && c->haveScene && c->hostLights.numDir + c->hostLights.numPoint > 8u)
+    return RTHIP_E_LIMIT;
+  c->pointShadows = on != 0; // (read when launches are queued: takes effect with the next render call)
+  return 0;
+}
+
 int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc* f)
 {
   if (!c || !camera || !f || f->width == 0 || f->height == 0 || f->numSamples == 0)
@@ -1075,6 +1157,8 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
     return RTHIP_E_STATE;
   if (f->maxDepth == 0 || f->maxDepth > kMaxDepthSlots || f->maxDepth > 254)
     return RTHIP_E_LIMIT;
+  if (c->pointShadows && c->hostLights.numDir + c->hostLights.numPoint > 8u)
+    return RTHIP_E_LIMIT; // one occlusion bit per shadowed light in an 8-bit mask
   const uint32_t ts = f->tileSize ? f->tileSize : 64u;
   if (ts < 8u || (ts & (ts - 1u)) || f->width > 65535u || f->height > 65535u)
     return RTHIP_E_ARG; // tiles are powers of two >= 8; tile origins are packed into 16 bits each
@@ -1140,7 +1224,8 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
     c->altPending = false;
     return 0;
   };
-  const bool grows = numSlots > c->rayO.n || (pipelinedFrame && numSlots > c->alt.rayO.n) || P64 * 3 > c->acc.n || g.numLocalTiles > c->tileIds.n || !c->camConsts.p || !c->totals.p ||
+  const bool grows = numSlots > c->rayO.n || (pipelinedFrame && numSlots > c->alt.rayO.n) ||
+                     (c->materialsOn && (numSlots > c->alb.n || (pipelinedFrame && numSlots > c->alt.alb.n))) || P64 * 3 > c->acc.n || g.numLocalTiles > c->tileIds.n || !c->camConsts.p || !c->totals.p ||
                      (aovDepths && (size_t)P64 * widest.samples * aovDepths > c->aovTri.n);
   if (grows && (rc = quiesce()))
     return rc;

@@ -97,9 +97,54 @@ def multi_model_scene():
 
 
 def glb_meshes(name):
-    """Meshes of the reference's res/models/<name>.glb (fixture: tests/golden/glb_meshes.npz, one per mesh primitive)."""
+    """Meshes of the reference's res/models/<name>.glb (fixture: tests/golden/glb_meshes.npz, one per mesh primitive), each
+    with its texture coordinates and its primitive's glTF material factors (read only with the scene option "materials")."""
     z = np.load(os.path.join(GOLDEN, "glb_meshes.npz"))
-    return [Mesh.from_arrays(z["%s_%d_positions" % (name, k)], z["%s_%d_indices" % (name, k)]) for k in range(int(z[name + "_count"]))]
+    out = []
+    for k in range(int(z[name + "_count"])):
+        m = Mesh.from_arrays(z["%s_%d_positions" % (name, k)], z["%s_%d_indices" % (name, k)], z["%s_%d_texcoords" % (name, k)])
+        m.set_material(_capi.MAT_FACTORS, z["%s_%d_base_color" % (name, k)], z["%s_%d_emissive" % (name, k)])
+        out.append(m)
+    return out
+
+
+def checker_texture(w, h, a=(0.9, 0.2, 0.1), b=(0.1, 0.3, 0.9), cells=4):
+    """A w x h RGB checkerboard with a per-texel ramp on top (so neighbouring texels differ and an off-by-one shows)."""
+    y, x = np.mgrid[0:h, 0:w]
+    on = (((x * cells) // w + (y * cells) // h) & 1).astype(bool)
+    t = np.where(on[..., None], np.asarray(a, np.float32), np.asarray(b, np.float32)).astype(np.float32)
+    t *= (np.float32(0.5) + np.float32(0.5) * ((x + 3 * y) % 17).astype(np.float32)[..., None] / np.float32(16))
+    return np.ascontiguousarray(t, np.float32)
+
+
+def quad_mesh(size=1.0, uv_scale=1.0, tilt=0.02):
+    """A square facing +y, two triangles, texture coordinates covering [0, uv_scale]^2.  It rises by 2 * tilt * size along x:
+    an exactly flat model has a zero-thickness box, which the reference's strict slab test (AABB.h:59) never passes."""
+    s = float(size)
+    r = float(tilt) * s
+    p = np.array([[-s, -r, -s], [s, r, -s], [s, r, s], [-s, -r, s]], np.float32)
+    t = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32) * np.float32(uv_scale)
+    return Mesh.from_arrays(p, np.array([[0, 2, 1], [0, 3, 2]], np.uint32), t)
+
+
+def materials_scene():
+    """Every material feature at once: a textured floor (albedo + emissive textures, texture coordinates running past 1 so
+    the edge clamp is hit), a cube with the reference's stub material (albedo = texture coordinates), a soup with plain
+    factors, an emissive panel, a model left at the default material; one directional and two point lights (one of them
+    behind the cube as seen from the floor, so its shadow rays matter)."""
+    floor = quad_mesh(3.0, 1.25)
+    floor.set_material(_capi.MAT_FACTORS, (0.9, 0.8, 0.7), (0.05, 0.1, 0.02), checker_texture(16, 8), checker_texture(5, 7, (1, 1, 0), (0, 1, 1), 3))
+    cube = Mesh.cube()
+    cube.set_material(_capi.MAT_STUB)
+    soup = Mesh.soup(400, 11, 0.35)
+    soup.set_material(_capi.MAT_FACTORS, (0.25, 0.5, 0.95), (0, 0, 0))
+    panel = quad_mesh(0.6)
+    panel.set_material(_capi.MAT_FACTORS, (0.2, 0.2, 0.2), (2.0, 1.5, 0.5))
+    plain = Mesh.cube()
+    meshes = [(floor, translate(0, -1.0, 0)), (cube, translate(-0.9, -0.3, 0.2) @ scale(0.6)), (soup, translate(0.8, 0.2, -0.3)),
+              (panel, translate(0.0, 1.6, 0.0)), (plain, translate(1.7, -0.6, 0.9) @ scale(0.35))]
+    return SceneSpec("materials", meshes, dict(position=(2.5, 2.2, 4.5), target=(0, -0.2, 0), S_O=6, f=0, A=0),
+                     point_lights=[((-0.9, 0.9, 0.2), (1.0, 0.9, 0.8), 4.0), ((1.5, 0.4, 1.5), (0.3, 0.6, 1.0), 3.0)])
 
 
 def box_glb_scene():

@@ -42,6 +42,7 @@ PModel cloneModel(const Model& src)
   m->texCoords = src.texCoords;
   m->normals = src.normals;
   m->indices = src.indices;
+  m->material = src.material; // textures are shared, not copied
   return m;
 }
 } // namespace
@@ -96,6 +97,51 @@ void rt_mesh_copy(const rt_mesh* m, float* positions3, uint32_t* indices3)
     std::memcpy(positions3, m->model->positions.data(), m->model->positions.size() * sizeof(vec3));
   if (indices3)
     std::memcpy(indices3, m->model->indices.data(), m->model->indices.size() * sizeof(uvec3));
+}
+int rt_mesh_set_material(rt_mesh* m, uint32_t kind, const float baseColor[3], const float emissive[3], const float* albedoTexels, uint32_t albedoW,
+                         uint32_t albedoH, const float* emissiveTexels, uint32_t emissiveW, uint32_t emissiveH)
+{
+  if (!m || !baseColor || !emissive || kind > 1u)
+    return RTHIP_E_ARG;
+  if ((albedoTexels && (!albedoW || !albedoH)) || (emissiveTexels && (!emissiveW || !emissiveH)))
+    return RTHIP_E_ARG;
+  if ((uint64_t)albedoW * albedoH > (1u << 28) || (uint64_t)emissiveW * emissiveH > (1u << 28))
+    return RTHIP_E_LIMIT;
+  auto texture = [](const float* rgb, uint32_t w, uint32_t h) -> PTexture {
+    if (!rgb)
+      return nullptr;
+    auto t = std::make_shared<Texture>();
+    t->width = (int)w, t->height = (int)h;
+    t->textureData.resize((size_t)w * h);
+    for (size_t k = 0; k < t->textureData.size(); ++k)
+      t->textureData[k] = vec3{rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2]};
+    return t;
+  };
+  Material& mt = m->model->material;
+  mt.kind = kind == 0u ? MaterialKind::ReferenceStub : MaterialKind::Factors;
+  mt.baseColor = vec3{baseColor[0], baseColor[1], baseColor[2]};
+  mt.emissive = vec3{emissive[0], emissive[1], emissive[2]};
+  mt.albedoTexture = texture(albedoTexels, albedoW, albedoH);
+  mt.emissiveTexture = texture(emissiveTexels, emissiveW, emissiveH);
+  return 0;
+}
+int rt_mesh_get_material(const rt_mesh* m, uint32_t* kind, float baseColor[3], float emissive[3])
+{
+  if (!m)
+    return RTHIP_E_ARG;
+  const Material& mt = m->model->material;
+  if (kind)
+    *kind = (uint32_t)mt.kind;
+  if (baseColor)
+    baseColor[0] = mt.baseColor.x, baseColor[1] = mt.baseColor.y, baseColor[2] = mt.baseColor.z;
+  if (emissive)
+    emissive[0] = mt.emissive.x, emissive[1] = mt.emissive.y, emissive[2] = mt.emissive.z;
+  return 0;
+}
+void rt_mesh_copy_texcoords(const rt_mesh* m, float* texCoords2)
+{
+  if (m && texCoords2)
+    std::memcpy(texCoords2, m->model->texCoords.data(), m->model->texCoords.size() * sizeof(vec2));
 }
 void rt_mesh_destroy(rt_mesh* m) { delete m; }
 
@@ -193,6 +239,10 @@ int rt_set_option(rt_renderer* r, const char* name, double value)
     fo.threads = u;
   else if (n == "deviceBvh")
     fo.deviceBuild = value != 0;
+  else if (n == "materials")
+    r->hip->getScene()->shading.materials = value != 0;
+  else if (n == "pointShadows")
+    r->hip->getScene()->shading.pointShadows = value != 0;
   else if (n == "originBoundScale")
     fo.originBoundScale = (float)value;
   else if (n == "countWork")
@@ -346,6 +396,24 @@ int rt_get_flat(rt_renderer* r, const rtflat_info** info, const rtflat_model_nod
     *tris = f.tris.data();
   if (buildSeconds)
     *buildSeconds = f.buildSeconds;
+  return 0;
+}
+int rt_get_flat_shading(rt_renderer* r, const rtflat_shade** shade, const rtflat_material** materials, uint32_t* numMaterials, const float** texels,
+                        uint64_t* numTexels)
+{
+  if (!r || !r->generated)
+    return RTHIP_E_STATE;
+  const HIPScene::FlatShading& fs = r->hip->getScene()->flattenedShading();
+  if (shade)
+    *shade = fs.shade.empty() ? nullptr : fs.shade.data();
+  if (materials)
+    *materials = fs.materials.empty() ? nullptr : fs.materials.data();
+  if (numMaterials)
+    *numMaterials = (uint32_t)fs.materials.size();
+  if (texels)
+    *texels = fs.texels.empty() ? nullptr : fs.texels.data();
+  if (numTexels)
+    *numTexels = fs.texels.size() / 3;
   return 0;
 }
 rthip_ctx* rt_context(rt_renderer* r) { return r ? r->hip->context() : nullptr; }

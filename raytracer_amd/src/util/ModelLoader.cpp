@@ -370,6 +370,25 @@ std::vector<PModel> loadGlb(const std::string& path)
       for (size_t k = 0; k + 2 < idx.size(); k += 3)
         if (idx[k] < pos.count && idx[k + 1] < pos.count && idx[k + 2] < pos.count)
           model->indices.push_back(uvec3{idx[k], idx[k + 1], idx[k + 2]});
+      // the primitive's material: the two factors of glTF 2.0 that map onto Material (pbrMetallicRoughness.baseColorFactor, RGB of
+      // RGBA, default 1; emissiveFactor, default 0).  Image textures (PNG / JPEG inside the file) are not decoded.
+      model->material.kind = MaterialKind::Factors;
+      model->material.baseColor = vec3{1.0f, 1.0f, 1.0f};
+      model->material.emissive = vec3{0.0f, 0.0f, 0.0f};
+      const Json* materials = root.get("materials");
+      const long mat = prim.integer("material", -1);
+      if (materials && mat >= 0 && (size_t)mat < materials->items.size())
+      {
+        auto rgb = [](const Json* a, vec3& out) {
+          if (a && a->kind == Json::Array && a->items.size() >= 3 && a->items[0].kind == Json::Number && a->items[1].kind == Json::Number &&
+              a->items[2].kind == Json::Number)
+            out = vec3{(float)a->items[0].number, (float)a->items[1].number, (float)a->items[2].number};
+        };
+        const Json& m = materials->items[(size_t)mat];
+        if (const Json* pbr = m.get("pbrMetallicRoughness"))
+          rgb(pbr->get("baseColorFactor"), model->material.baseColor);
+        rgb(m.get("emissiveFactor"), model->material.emissive);
+      }
       if (!model->indices.empty())
         result.push_back(std::move(model));
     }

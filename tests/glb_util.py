@@ -52,6 +52,42 @@ def parse_glb(data):
     return out
 
 
+def parse_glb_shading(data):
+    """[(texcoords float32 (V,2) -- zeros without TEXCOORD_0 --, baseColorFactor rgb, emissiveFactor rgb)] for the primitives
+    parse_glb keeps, in the same order; glTF defaults (1,1,1) / (0,0,0) where a primitive or its material says nothing."""
+    magic, version, total = struct.unpack_from("<III", data, 0)
+    at, doc, binary = 12, None, b""
+    while at + 8 <= min(total, len(data)):
+        length, kind = struct.unpack_from("<II", data, at)
+        at += 8
+        chunk = data[at:at + length]
+        if kind == 0x4E4F534A and doc is None:
+            doc = json.loads(chunk.decode("utf-8"))
+        elif kind == 0x004E4942 and not binary:
+            binary = bytes(chunk)
+        at += (length + 3) & ~3
+    out = []
+    for mesh in doc.get("meshes", []):
+        for prim in mesh.get("primitives", []):
+            if prim.get("mode", 4) != 4 or "POSITION" not in prim.get("attributes", {}):
+                continue
+            n = doc["accessors"][prim["attributes"]["POSITION"]]["count"]
+            uv = np.zeros((n, 2), np.float32)
+            if "TEXCOORD_0" in prim["attributes"]:
+                a = _accessor(doc, binary, prim["attributes"]["TEXCOORD_0"])
+                if a.dtype == np.dtype("<f4") and a.shape == (n, 2):
+                    uv = a.astype(np.float32)
+            base, emissive = np.ones(3, np.float32), np.zeros(3, np.float32)
+            if "material" in prim and prim["material"] < len(doc.get("materials", [])):
+                m = doc["materials"][prim["material"]]
+                if "baseColorFactor" in m.get("pbrMetallicRoughness", {}):
+                    base = np.asarray(m["pbrMetallicRoughness"]["baseColorFactor"][:3], np.float64).astype(np.float32)
+                if "emissiveFactor" in m:
+                    emissive = np.asarray(m["emissiveFactor"][:3], np.float64).astype(np.float32)
+            out.append((uv, base, emissive))
+    return out
+
+
 def write_glb(primitives):
     """primitives: list of dicts(positions (V,3) float32, indices (T,3) or None, index_type 5121/5123/5125, interleave bool,
     mode int).  Returns the bytes of a .glb holding one mesh per primitive."""

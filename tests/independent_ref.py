@@ -87,10 +87,16 @@ class Scene:
     (transforms in math convention: column vectors, as the tests write them)."""
 
     def __init__(self, models, reference_edge_indexing=True):
+        """models: (positions, indices, transform) or (positions, indices, transform, texcoords, material) where material is
+        None or a dict(kind, base_color, emissive, albedo_texture, emissive_texture) as Mesh.set_material takes it."""
         self.positions, self.indices, self.edges, self.normals, self.refs, self.boxes = [], [], [], [], [], []
+        self.texcoords, self.materials = [], []
         pos_off = idx_off = 0
-        for p, idx, m in models:
+        for entry in models:
+            p, idx, m = entry[:3]
             p = np.asarray(p, F).reshape(-1, 3)
+            self.texcoords.append(np.asarray(entry[3], F).reshape(-1, 2) if len(entry) > 3 and entry[3] is not None else np.zeros((len(p), 2), F))
+            self.materials.append(entry[4] if len(entry) > 4 else None)
             idx = np.asarray(idx, np.int64).reshape(-1, 3)
             m = np.asarray(m, F)
             cols = [m[:, k] for k in range(4)]  # glm columns
@@ -112,8 +118,69 @@ class Scene:
         self.position_pool = np.concatenate(self.positions)
         self.edges_pool = np.concatenate(self.edges)
         self.normal_pool = np.concatenate(self.normals)
+        self.texcoord_pool = np.concatenate(self.texcoords)
         self.reference_edge_indexing = reference_edge_indexing
         self.tree = self._pair_models()
+
+    # ---- HitInfo::texCoords (CPUScene.cpp:201-203, 217-219) and the material behind a hit
+    def hit_texcoords(self, tri, o, d):
+        """tri: pool triangle indices of the winners (R,), o / d their rays: the texture coordinates the intersector attaches"""
+        uv = np.zeros((len(tri), 2), F)
+        for m, (pos_off, _, idx_off, n) in enumerate(self.refs):
+            sel = (tri >= idx_off) & (tri < idx_off + n)
+            if not sel.any():
+                continue
+            local = tri[sel] - idx_off
+            p0, e0, e1, _, _ = self._operands(m)
+            idx = self.indices[m][local]
+            t0, t1, t2 = (self.texcoord_pool[pos_off + idx[:, k]] for k in range(3))
+            P0, E0, E1, O, D = p0[local], e0[local], e1[local], o[sel], d[sel]
+            with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+                sv = O - P0
+                s1 = cross(D, E1)
+                s2 = cross(sv, E0)
+                frac = F(1.0) / dot(s1, E0)
+                y = (dot(s1, sv) * frac)[:, None]
+                z = (dot(s2, D) * frac)[:, None]
+                b3 = F(1.0) - y - z
+                uv[sel] = (t0 * y + t1 * z) + t2 * b3
+        return uv
+
+    @staticmethod
+    def _sample(texture, uv):
+        """Texture::sample (Texture.cpp:3-8); coordinates outside [0,1) clamp to the edge texels (the documented convention
+        where the reference indexes out of bounds)"""
+        tex = np.asarray(texture, F)
+        h, w = tex.shape[:2]
+
+        def index(c, size):
+            f = c * F(size)
+            with np.errstate(invalid="ignore"):
+                inside = np.where(f >= F(size), size - 1, np.trunc(np.where(f >= 0, f, 0)).astype(np.int64))
+            return np.where(f >= 0, inside, 0)
+        return tex[index(uv[:, 1], h), index(uv[:, 0], w)]
+
+    def evaluate_materials(self, tri, uv):
+        """(albedo, emissive) per hit: Material::evaluate for kind 0, factor [* texture sample] for kind 1"""
+        albedo = np.tile(np.array([0, 1, 0], F), (len(tri), 1))
+        emissive = np.zeros((len(tri), 3), F)
+        for m, (_, _, idx_off, n) in enumerate(self.refs):
+            sel = (tri >= idx_off) & (tri < idx_off + n)
+            spec = self.materials[m]
+            if not sel.any() or spec is None:
+                continue
+            if spec["kind"] == 0:
+                albedo[sel] = np.concatenate([uv[sel], np.zeros((sel.sum(), 1), F)], axis=1)
+                emissive[sel] = 0
+                continue
+            a = np.tile(np.asarray(spec["base_color"], F), (sel.sum(), 1))
+            e = np.tile(np.asarray(spec["emissive"], F), (sel.sum(), 1))
+            if spec.get("albedo_texture") is not None:
+                a = a * self._sample(spec["albedo_texture"], uv[sel])
+            if spec.get("emissive_texture") is not None:
+                e = e * self._sample(spec["emissive_texture"], uv[sel])
+            albedo[sel], emissive[sel] = a, e
+        return albedo, emissive
 
     def _pair_models(self):
         """CPUScene.cpp:67-105.  Returns nested tuples: ('leaf', model) | ('node', box, left, right)."""
@@ -231,9 +298,10 @@ class Scene:
         return walk(self.tree, np.ones(o.shape[0], bool))
 
 
-def render_first_hit(scene, cam, W, H, num_samples, samp, dir_lights, point_lights):
+def render_first_hit(scene, cam, W, H, num_samples, samp, dir_lights, point_lights, materials=False, point_shadows=False):
     """One sample pass with a depth cap of 1: returns (accumulator contribution radiance/N (H, W, 3), triId (H, W), shadow bits
-    (H, W), t (H, W))."""
+    (H, W), t (H, W)).  materials: albedo / emissive from the models' materials instead of CPUScene.cpp:243-247;
+    point_shadows: point lights shadowed as in src/metal/Compute.metal:238-254."""
     o, d, _ = primary_rays(cam, W, H, samp)
     o, d = np.broadcast_to(o, d.shape).reshape(-1, 3).astype(F), d.reshape(-1, 3)
     t, tri = scene.closest(o, d)
@@ -244,9 +312,12 @@ def render_first_hit(scene, cam, W, H, num_samples, samp, dir_lights, point_ligh
         oh, dh, th, ih = o[hit], d[hit], t[hit], tri[hit]
         n = scene.normal_pool[ih]
         pos = oh + dh * th[:, None]
-        albedo = np.array([0, 1, 0], F)
+        albedo = np.tile(np.array([0, 1, 0], F), (len(th), 1))
+        emissive = np.zeros((len(th), 3), F)
+        if materials:
+            albedo, emissive = scene.evaluate_materials(ih, scene.hit_texcoords(ih, oh, dh))
         rad = np.zeros((len(th), 3), F)
-        rad = rad + (np.ones(3, F) * np.zeros(3, F)) * F(1.0)  # emissive term: material * emissive * payload.emissive = 0
+        rad = rad + (np.ones(3, F) * emissive) * F(1.0)  # CPUScene.cpp:27: material * emissive * payload.emissive
         bits = np.zeros(len(th), np.uint8)
         for l, (ldir, lcol) in enumerate(dir_lights):
             ldir, lcol = np.asarray(ldir, F), np.asarray(lcol, F)
@@ -255,14 +326,20 @@ def render_first_hit(scene, cam, W, H, num_samples, samp, dir_lights, point_ligh
             diffuse = vmax(dot(n, -ldir), F(0.0))
             e = (albedo * diffuse[:, None]) * lcol + F(0.03)
             rad = np.where(occ[:, None], rad, rad + e)
-        for lpos, lcol, att in point_lights:
+        for l, (lpos, lcol, att) in enumerate(point_lights):
             lpos, lcol = np.asarray(lpos, F), np.asarray(lcol, F)
             ldir = lpos - pos
             dist = np.sqrt(dot(ldir, ldir))
             illum = vmax(F(1) - dist / F(att), F(0.0))
             diffuse = vmax(dot(n, ldir), F(0.0))
             e = (albedo * diffuse[:, None]) * lcol + F(0.03)
-            rad = rad + illum[:, None] * e
+            if point_shadows:
+                # Compute.metal:240-246: from just off the surface toward the light, t in [0, 1]
+                occ = scene.occluded((pos + n * F(1e-3)).astype(F), ldir.astype(F), tmin=F(0.0), tmax=F(1.0))
+                bits |= (occ.astype(np.uint8) << (len(dir_lights) + l))
+                rad = np.where(occ[:, None], rad, rad + illum[:, None] * e)
+            else:
+                rad = rad + illum[:, None] * e
         radiance[hit] = rad
         shadow[hit] = bits
     tri_id = np.where(hit, tri, 0xFFFFFFFF).astype(np.uint32)

@@ -13,15 +13,18 @@ class SceneSpec(_ps.SceneSpec):
     def oracle_camera(self):
         return ob.make_camera(**self.camera)
 
-    def build_oracle(self, fix_edge_offset=False):
+    def build_oracle(self, fix_edge_offset=False, materials=False, point_shadows=False):
         s = ob.OracleScene(fix_edge_offset=fix_edge_offset)
         for d, c in self.dir_lights:
             s.add_directional_light(d, c)
         for p, c, a in self.point_lights:
             s.add_point_light(p, c, a)
-        for mesh, t in self.meshes:
+        for k, (mesh, t) in enumerate(self.meshes):
             pos, idx = mesh.arrays()
-            s.add_model(pos, idx, t)
+            s.add_model(pos, idx, t, texcoords=mesh.texcoords())
+            if mesh.material_spec is not None:
+                s.set_model_material(k, **mesh.material_spec)
+        s.set_shading(materials, point_shadows)
         s.generate()
         return s
 
@@ -44,5 +47,6 @@ box_glb_scene = _with_oracle(_ps.box_glb_scene)
 town_hall_scene = _with_oracle(_ps.town_hall_scene)
 soup1m_scene = _with_oracle(_ps.soup1m_scene)
 hf10m_scene = _with_oracle(_ps.hf10m_scene)
+materials_scene = _with_oracle(_ps.materials_scene)
 bunny_mesh = _ps.bunny_mesh
 glb_meshes = _ps.glb_meshes
