@@ -1,5 +1,7 @@
 """Probe (not a test): frame time with batches overlapped / one at a time, and per-kernel-family device time when every
-kernel runs alone.   usage: python tools/kernel_probe.py <workload> [frames]   (workloads: bench.py's)"""
+kernel runs alone.   usage: python tools/kernel_probe.py <workload> [frames]   (workloads: bench.py's)
+RT_PROBE_MATERIALS=1: every mesh gets planar texture coordinates and a 256x256 albedo texture, scene option "materials" on;
+RT_PROBE_POINT_SHADOWS=1: point lights cast shadow rays."""
 import sys
 import time
 
@@ -14,8 +16,22 @@ def main():
     spec = wl["spec"]()
     W, H, N, depth = wl["width"], wl["height"], wl["spp"], wl["max_depth"]
     import os
+    extra = {}
+    if os.environ.get("RT_PROBE_MATERIALS"):
+        import numpy as np
+        import raytracer_amd as ra
+        textured = []
+        for mesh, t in spec.meshes:
+            p, i = mesh.arrays()
+            m = ra.Mesh.from_arrays(p, i, np.ascontiguousarray(p[:, [0, 2]] * np.float32(0.45) + np.float32(0.5)))
+            m.set_material(ra.capi.MAT_FACTORS, (0.9, 0.9, 0.9), (0, 0, 0), ra.scenes.checker_texture(256, 256, cells=32))
+            textured.append((m, t))
+        spec.meshes = textured
+        extra["materials"] = 1
+    if os.environ.get("RT_PROBE_POINT_SHADOWS"):
+        extra["pointShadows"] = 1
     for pipelining in ((0,) if os.environ.get("RT_PROBE_ALONE") else (1, 0)):
-        r = spec.build_product(options=dict(maxDepth=depth, pipelining=pipelining))
+        r = spec.build_product(options=dict(maxDepth=depth, pipelining=pipelining, **extra))
         cam = spec.product_camera()
         for rep in range(2):
             t = time.perf_counter()
