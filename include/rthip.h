@@ -81,7 +81,9 @@ int rthip_create(int device, rthip_ctx** out);
 int rthip_destroy(rthip_ctx* ctx);
 
 /* Uploads the flattened scene (copies).  Takes over CPUScene::createRayTracingHierarchy's result
- * (src/cpu/CPUScene.cpp:67-105) and the pools intersectModel reads (src/scene/Scene.h:45-51). */
+ * (src/cpu/CPUScene.cpp:67-105) and the pools intersectModel reads (src/scene/Scene.h:45-51).
+ * Lights: up to 32 directional lights (each casts a shadow ray per hit, one occlusion bit per light and path) and up to
+ * 65536 point lights; beyond that RTHIP_E_LIMIT (the reference's vectors are unbounded, src/scene/Scene.h:53-54). */
 int rthip_upload_scene(rthip_ctx* ctx, const rtflat_info* info, const rtflat_model_node* modelNodes, const rtflat_node* nodes,
                        const rtflat_tri* tris, const rthip_dir_light* dirLights, uint32_t numDirLights,
                        const rthip_point_light* pointLights, uint32_t numPointLights);
@@ -112,7 +114,8 @@ int rthip_upload_materials(rthip_ctx* ctx, const rtflat_shade* shade, uint32_t n
 /* on != 0: point lights cast shadow rays too, the way the reference's Metal kernel does (src/metal/Compute.metal:238-254:
  * origin = hit + normal * 1e-3, direction = light - hit, t in [0, 1]); the CPU path leaves them unshadowed
  * (src/cpu/CPUScene.cpp:42, commented out) and so does this backend by default.  Occlusion bits of the point lights
- * follow those of the directional lights in the shadow AOV, so on requires numDir + numPoint <= 8 (RTHIP_E_LIMIT). */
+ * follow those of the directional lights in the path's 32-bit mask (the shadow AOV shows the low 8), so on requires
+ * numDir + numPoint <= 32 (RTHIP_E_LIMIT). */
 int rthip_set_point_shadows(rthip_ctx* ctx, int on);
 
 /* Starts a frame: allocates and clears accumulator/image for the tiles of `frame`

@@ -29,6 +29,12 @@ class Camera(C.Structure):  # rthip_camera == the reference's Camera (src/util/C
                 ("S_O", C.c_float), ("f", C.c_float), ("A", C.c_float)]
 
 
+class FrameDesc(C.Structure):  # rthip_frame_desc
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("numSamples", C.c_uint32), ("maxDepth", C.c_uint32),
+                ("aovDepths", C.c_uint32), ("tileSize", C.c_uint32), ("numTiles", C.c_uint32), ("pad", C.c_uint32),
+                ("tileIds", C.POINTER(C.c_uint32))]
+
+
 class Counters(C.Structure):  # rthip_counters
     _fields_ = [("extendPrimary", C.c_uint64), ("extendSecondary", C.c_uint64), ("shadow", C.c_uint64),
                 ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64), ("nonFiniteAccepts", C.c_uint64),
@@ -108,6 +114,7 @@ def hip_lib():
         L.rthip_get_kernel_times.argtypes = [vp, fp, up]
         L.rthip_upload_materials.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64]
         L.rthip_set_point_shadows.argtypes = [vp, C.c_int]
+        L.rthip_begin.argtypes = [vp, C.POINTER(Camera), C.POINTER(FrameDesc)]
         _hip = L
     return _hip
 

@@ -27,7 +27,8 @@ constexpr uint32_t kFetchStride = 64;  // counters 256 B apart
 constexpr uint32_t kMaxTraceLaunches = 2 * (64 + 2); // two traversal launches per depth, depth <= kMaxDepthSlots
 constexpr uint8_t kDead = 0xff;        // path finished, radiance in s0
 constexpr uint8_t kDeadZero = 0xfe;    // path finished with exactly zero radiance (primary miss) or pixel outside the image
-constexpr uint32_t kMaxLights = 8;
+constexpr uint32_t kMaxShadowedLights = 32; // lights that cast shadow rays: one occlusion bit each in a 32-bit mask per path
+constexpr uint32_t kMaxPointLights = 1u << 16;
 constexpr size_t kMaxTimedLaunches = 16384; // event pairs kept by the kernel timer between two reads
 constexpr uint32_t kMaxDepthSlots = 64;
 
@@ -61,8 +62,8 @@ struct DeviceScene
 
 struct Lights
 {
-  rthip_dir_light dir[kMaxLights];
-  rthip_point_light point[kMaxLights];
+  rthip_dir_light dir[kMaxShadowedLights];
+  const rthip_point_light* point; // device array of numPoint entries (any number while they cast no shadow rays)
   uint32_t numDir, numPoint;
 };
 
@@ -103,7 +104,7 @@ struct PathBuffers
   float2* s1;    // material.y, material.z                       (not written by the last shaded depth)
   float* nz;     // face normal z of the previous hit
   uint8_t* live; // depth at which the path is waiting, kDead / kDeadZero when finished
-  uint8_t* mask; // occlusion bits of the previous hit's shadow rays
+  uint32_t* mask; // occlusion bits of the previous hit's shadow rays (bit l = light l occluded)
   float4* alb;   // albedo of the previous hit (materials only; without them it is the constant of CPUScene.cpp:245)
 };
 

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 6)) void k_tra
       a.pb.live[slot] = kDead;
     }
     else
-      a.pb.mask[slot] = (uint8_t)occluded;
+      a.pb.mask[slot] = occluded;
   };
 
   for (;;)

@@ -159,6 +159,7 @@ struct rthip_ctx
   DevBuf<rtflat_node> nodes;
   DevBuf<rtflat_tri> tris;
   DevBuf<Lights> lights;
+  DevBuf<rthip_point_light> pointLights;
   Lights hostLights{};
   // shading inputs (rthip_upload_materials): per-triangle texture coordinates + material index, materials, texel pool
   DevBuf<rtflat_shade> shade;
@@ -180,7 +181,8 @@ struct rthip_ctx
   DevBuf<float2> s1;
   DevBuf<float> nz;
   DevBuf<uint2> hit;
-  DevBuf<uint8_t> live, mask, anyOut;
+  DevBuf<uint8_t> live, anyOut;
+  DevBuf<uint32_t> mask;
   DevBuf<float> acc, img, rowScratch;
   DevBuf<uint32_t> aovTri;
   DevBuf<uint8_t> aovShadow;
@@ -216,8 +218,8 @@ struct rthip_ctx
     DevBuf<float2> s1;
     DevBuf<float> nz;
     DevBuf<uint2> hit;
-    DevBuf<uint8_t> live, mask;
-    DevBuf<uint32_t> spill, spill2, fetch, listA, listB;
+    DevBuf<uint8_t> live;
+    DevBuf<uint32_t> mask, spill, spill2, fetch, listA, listB;
   } alt;
   hipEvent_t evDone = nullptr;   // this slot's "batch finished" event (recorded after every batch)
   hipEvent_t evFrame = nullptr;  // fork point: the second slot's stream waits for the frame prologue on the main stream
@@ -712,6 +714,25 @@ const char* rthip_error_string(int code)
   }
 }
 
+// the light block of a scene: directional lights inline, point lights in an array of their own (the block points at it)
+static int uploadLights(rthip_ctx* c, const rthip_dir_light* dirLights, uint32_t numDirLights, const rthip_point_light* pointLights, uint32_t numPointLights)
+{
+  int rc;
+  if ((rc = c->lights.ensure(1)) || (rc = c->pointLights.ensure(std::max(1u, numPointLights))))
+    return rc;
+  Lights& L = c->hostLights;
+  std::memset(&L, 0, sizeof(L));
+  L.numDir = numDirLights;
+  L.numPoint = numPointLights;
+  L.point = c->pointLights.p;
+  for (uint32_t i = 0; i < numDirLights; ++i)
+    L.dir[i] = dirLights[i];
+  if (numPointLights)
+    HIPCHK(hipMemcpy(c->pointLights.p, pointLights, sizeof(rthip_point_light) * numPointLights, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->lights.p, &L, sizeof(L), hipMemcpyHostToDevice));
+  return 0;
+}
+
 static int createContext(rthip_ctx* c, int device)
 {
   c->device = device;
@@ -832,7 +853,7 @@ int rthip_upload_scene(rthip_ctx* c, const rtflat_info* info, const rtflat_model
     return RTHIP_E_ARG;
   if (info->numModelNodes == 0 || info->numTris == 0 || info->numNodes == 0)
     return RTHIP_E_ARG;
-  if (numDirLights > kMaxLights || numPointLights > kMaxLights || info->numTris >= (1u << 28) - 1u)
+  if (numDirLights > kMaxShadowedLights || numPointLights > kMaxPointLights || info->numTris >= (1u << 28) - 1u)
     return RTHIP_E_LIMIT;
   // the per-lane stack must hold up to three postponed children per level of the deepest chain
   if (3 * info->maxDepthBlas + 2 > kMaxStack)
@@ -885,15 +906,8 @@ int rthip_upload_scene(rthip_ctx* c, const rtflat_info* info, const rtflat_model
   HIPCHK(hipMemcpy(c->modelNodes.p, modelNodes, sizeof(rtflat_model_node) * info->numModelNodes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->nodes.p, nodes, sizeof(rtflat_node) * info->numNodes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->tris.p, tris, sizeof(rtflat_tri) * info->numTris, hipMemcpyHostToDevice));
-  Lights& L = c->hostLights;
-  std::memset(&L, 0, sizeof(L));
-  L.numDir = numDirLights;
-  L.numPoint = numPointLights;
-  for (uint32_t i = 0; i < numDirLights; ++i)
-    L.dir[i] = dirLights[i];
-  for (uint32_t i = 0; i < numPointLights; ++i)
-    L.point[i] = pointLights[i];
-  HIPCHK(hipMemcpy(c->lights.p, &L, sizeof(L), hipMemcpyHostToDevice));
+  if (int rcLights = uploadLights(c, dirLights, numDirLights, pointLights, numPointLights))
+    return rcLights;
   c->info = *info;
   c->info.maxDepthBlas = deepest;
   c->spillCap = 3 * deepest + 2 > kStackLds ? 3 * deepest + 2 - kStackLds : 1u;
@@ -915,7 +929,7 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
     return RTHIP_E_ARG;
   if (info->numModelNodes == 0 || info->numTris == 0)
     return RTHIP_E_ARG;
-  if (numDirLights > kMaxLights || numPointLights > kMaxLights || info->numTris >= (1u << 28) - 1u)
+  if (numDirLights > kMaxShadowedLights || numPointLights > kMaxPointLights || info->numTris >= (1u << 28) - 1u)
     return RTHIP_E_LIMIT;
   const uint32_t maxLeaf = std::max(1u, std::min(maxLeafTris, (uint32_t)RTFLAT_MAX_LEAF_TRIS));
   const uint32_t numTris = info->numTris;
@@ -1058,15 +1072,8 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
   if (3 * deepest + 2 > kMaxStack)
     return RTHIP_E_LIMIT;
   HIPCHK(hipMemcpy(c->modelNodes.p, modelNodes, sizeof(rtflat_model_node) * info->numModelNodes, hipMemcpyHostToDevice));
-  Lights& L = c->hostLights;
-  std::memset(&L, 0, sizeof(L));
-  L.numDir = numDirLights;
-  L.numPoint = numPointLights;
-  for (uint32_t i = 0; i < numDirLights; ++i)
-    L.dir[i] = dirLights[i];
-  for (uint32_t i = 0; i < numPointLights; ++i)
-    L.point[i] = pointLights[i];
-  HIPCHK(hipMemcpy(c->lights.p, &L, sizeof(L), hipMemcpyHostToDevice));
+  if (int rcLights = uploadLights(c, dirLights, numDirLights, pointLights, numPointLights))
+    return rcLights;
   info->numNodes = nodesUsed;
   info->maxDepthBlas = deepest;
   c->info = *info;
@@ -1143,7 +1150,7 @@ int rthip_set_point_shadows(rthip_ctx* c, int on)
 {
   if (!c)
     return RTHIP_E_ARG;
-  if (on && c->haveScene && c->hostLights.numDir + c->hostLights.numPoint > 8u)
+  if (on && c->haveScene && c->hostLights.numDir + c->hostLights.numPoint > kMaxShadowedLights)
     return RTHIP_E_LIMIT;
   c->pointShadows = on != 0; // (read when launches are queued: takes effect with the next render call)
   return 0;
@@ -1157,8 +1164,8 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
     return RTHIP_E_STATE;
   if (f->maxDepth == 0 || f->maxDepth > kMaxDepthSlots || f->maxDepth > 254)
     return RTHIP_E_LIMIT;
-  if (c->pointShadows && c->hostLights.numDir + c->hostLights.numPoint > 8u)
-    return RTHIP_E_LIMIT; // one occlusion bit per shadowed light in an 8-bit mask
+  if (c->pointShadows && c->hostLights.numDir + c->hostLights.numPoint > kMaxShadowedLights)
+    return RTHIP_E_LIMIT; // one occlusion bit per shadowed light in the 32-bit mask
   const uint32_t ts = f->tileSize ? f->tileSize : 64u;
   if (ts < 8u || (ts & (ts - 1u)) || f->width > 65535u || f->height > 65535u)
     return RTHIP_E_ARG; // tiles are powers of two >= 8; tile origins are packed into 16 bits each

@@ -1,5 +1,6 @@
 #include "hip/HIPRenderer.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
@@ -46,6 +47,27 @@ int HIPRenderer::beginFrameRender(Camera cam, RenderParameter params)
   frame.numTiles = (uint32_t)options.tiles.size();
   frame.tileIds = options.tiles.empty() ? nullptr : options.tiles.data();
   error = rthip_begin(ctx, &c, &frame);
+  if (error == RTHIP_E_BOUNDS)
+  {
+    // The padding of the BVH boxes was sized for ray origins within originBoundScale scene diagonals of the scene's centre
+    // (scene/BvhFlattener.h) and this camera stands further out.  The reference has no such limit: rebuild the acceleration
+    // data for a bound that holds this camera (half as far again, so that a camera backing away does not rebuild every
+    // frame) and start the frame again.  Anything still queued on the device finishes first (the upload synchronises).
+    const rtflat_info& info = scene->flattened().info;
+    double d2 = 0, diag2 = 0;
+    for (int k = 0; k < 3; ++k)
+    {
+      const double ctr = 0.5 * ((double)info.sceneLo[k] + (double)info.sceneHi[k]), ext = (double)info.sceneHi[k] - (double)info.sceneLo[k];
+      d2 += ((double)c.position[k] - ctr) * ((double)c.position[k] - ctr);
+      diag2 += ext * ext;
+    }
+    if (diag2 > 0 && std::isfinite(d2))
+    {
+      scene->options.originBoundScale = (float)std::max<double>(scene->options.originBoundScale * 2.0, 1.5 * std::sqrt(d2 / diag2));
+      scene->createRayTracingHierarchy();
+      error = scene->lastError() ? scene->lastError() : rthip_begin(ctx, &c, &frame);
+    }
+  }
   if (error)
     std::fprintf(stderr, "HIPRenderer: rthip_begin: %s\n", rthip_error_string(error));
   else

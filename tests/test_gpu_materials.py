@@ -134,9 +134,47 @@ def test_argument_checks():
     texels = np.zeros((16, 3), np.float32)
     assert L.rthip_upload_materials(ctx, shade.ctypes.data, 12, mats.ctypes.data, 1, texels.ctypes.data, 16) == 0
     r.close()
-    # more than eight shadowed lights do not fit the occlusion mask
-    many = scenes.SceneSpec("many_lights", spec.meshes, spec.camera, dir_lights=[(scenes.main_light_dir(), (1, 1, 1))] * 5,
-                            point_lights=[((0, 3, 0), (1, 1, 1), 5.0)] * 4)
+    # more than 32 shadowed lights do not fit the occlusion mask
+    many = scenes.SceneSpec("many_lights", spec.meshes, spec.camera, dir_lights=[(scenes.main_light_dir(), (1, 1, 1))] * 20,
+                            point_lights=[((0, 3, 0), (1, 1, 1), 5.0)] * 13)
+    many.build_product().close()  # fine while the point lights cast no shadow rays
     with pytest.raises(capi.RtError) as e:
         many.build_product(options=dict(pointShadows=1))
     assert e.value.code == capi.RTHIP_E_LIMIT
+    too_many = scenes.SceneSpec("too_many_lights", spec.meshes, spec.camera, dir_lights=[(scenes.main_light_dir(), (1, 1, 1))] * 33, point_lights=[])
+    with pytest.raises(capi.RtError) as e:
+        too_many.build_product()
+    assert e.value.code == capi.RTHIP_E_LIMIT
+
+
+def _many_lights(n_dir, n_point):
+    rng = np.random.default_rng(5)
+    dirs = rng.normal(size=(n_dir, 3)).astype(np.float32)
+    dirs[:, 1] = -np.abs(dirs[:, 1]) - np.float32(0.2)  # mostly from above
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True).astype(np.float32)
+    dir_lights = [(dirs[k], tuple(rng.random(3).astype(np.float32) * np.float32(0.2))) for k in range(n_dir)]
+    point_lights = [(tuple(rng.uniform(-2, 2, 3).astype(np.float32)), tuple(rng.random(3).astype(np.float32) * np.float32(0.3)), float(rng.uniform(2, 5)))
+                    for _ in range(n_point)]
+    return dir_lights, point_lights
+
+
+@pytest.mark.parametrize("n_dir,n_point,point_shadows", [(12, 40, False), (9, 14, True), (0, 32, True)])
+def test_many_lights_match_oracle_bitexact(n_dir, n_point, point_shadows):
+    """More lights than the 8 + 8 of round 1: up to 32 shadow-casting lights (32 occlusion bits per path), any number of
+    unshadowed point lights (the reference's vectors are unbounded, Scene.h:53-54); the shadow AOV carries the low 8 bits."""
+    base = scenes.multi_model_scene()
+    dir_lights, point_lights = _many_lights(n_dir, n_point)
+    spec = scenes.SceneSpec("lights_%d_%d" % (n_dir, n_point), base.meshes, base.camera, dir_lights=dir_lights, point_lights=point_lights)
+    _compare(spec, 144, 96, 2, 4, False, point_shadows)
+
+
+def test_a_camera_beyond_the_origin_bound_rebuilds_instead_of_failing():
+    """The BVH padding is sized for cameras within 4 scene diagonals of the scene (RTHIP_E_BOUNDS from rthip_begin beyond);
+    the reference has no such limit, so the renderer re-flattens for the camera it is given and carries on."""
+    base = scenes.multi_model_scene()
+    cam = dict(base.camera)
+    cam["position"] = tuple(np.float32(60.0) * np.asarray(base.camera["position"], np.float32) / np.float32(6.4))  # ~60 units away: > 4 diagonals
+    cam["sensor"] = (0.0036, 0.0024)  # a long lens, so the scene still covers pixels
+    spec = scenes.SceneSpec("far_camera", base.meshes, cam, dir_lights=base.dir_lights, point_lights=base.point_lights)
+    want = _compare(spec, 160, 120, 2, 5, False, False)
+    assert (want["tri_id"][:, 0] != 0xFFFFFFFF).sum() > 2000

@@ -338,9 +338,10 @@ def test_error_codes_of_the_kernel_abi():
     acc = np.zeros((8, 8, 3), np.float32)
     assert hl.rthip_read_accumulator(ctx, acc.ctypes.data_as(C.POINTER(C.c_float))) == ra.capi.RTHIP_E_STATE
     far = ra.make_camera(position=(500.0, 0.0, 0.0), target=(0, 0, 0), S_O=6, f=0, A=0)
-    with pytest.raises(ra.RtError) as e:
-        r.begin_frame(far, 64, 64, 1)
-    assert e.value.code == ra.capi.RTHIP_E_BOUNDS and "origin bound" in str(e.value)
+    frame = ra.capi.FrameDesc(width=64, height=64, numSamples=1, maxDepth=2)
+    assert hl.rthip_begin(ctx, C.byref(far), C.byref(frame)) == ra.capi.RTHIP_E_BOUNDS
+    assert "origin bound" in ra.capi.error_string(ra.capi.RTHIP_E_BOUNDS)
+    # (the renderer reacts to that code by re-flattening for the camera: tests/test_gpu_materials.py, far camera)
     with pytest.raises(ra.RtError) as e:
         r.begin_frame(spec.product_camera(), 70000, 64, 1)                        # tile origins are packed in 16 bits
     assert e.value.code == ra.capi.RTHIP_E_ARG
