@@ -56,7 +56,7 @@ int rt_add_mesh(rt_renderer*, const rt_mesh*, const float transform[16]);
 int rt_generate(rt_renderer*);                                                 /* Renderer::generate */
 
 /* options the reference hard-codes: name in {"maxDepth","aovDepths","tileSize","passesPerCall","chunkMs",
- * "referenceEdgeIndexing","maxLeafTriangles","sahBins","buildThreads","originBoundScale","materials" (1: a hit's albedo / emissive come
+ * "referenceEdgeIndexing","maxLeafTriangles","sahBins","traversalCost","buildThreads","originBoundScale","materials" (1: a hit's albedo / emissive come
  * from its mesh's material instead of the constants of src/cpu/CPUScene.cpp:243-247), "pointShadows" (1: point lights cast shadow
  * rays as in src/metal/Compute.metal:238-254; needs <= 32 lights in all), "deviceBvh" (1: the triangle-level BVH is
  * built on the device, rthip_upload_scene_build, instead of by the host's binned-SAH builder),"countWork","kernelTiming","fusedPrimary","pipelining","overlapShadow"};

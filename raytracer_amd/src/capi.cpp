@@ -235,6 +235,8 @@ int rt_set_option(rt_renderer* r, const char* name, double value)
     fo.maxLeafTriangles = u;
   else if (n == "sahBins")
     fo.sahBins = u;
+  else if (n == "traversalCost")
+    fo.traversalCost = (float)std::max(0.0, value);
   else if (n == "buildThreads")
     fo.threads = u;
   else if (n == "deviceBvh")

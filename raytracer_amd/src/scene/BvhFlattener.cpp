@@ -102,6 +102,7 @@ struct BlasBuilder
   std::atomic<uint32_t>* nextNode;
   uint32_t recordBase;    // first rtflat_tri record of this model
   uint32_t maxLeaf, bins;
+  float traversalCost = 1.0f;
   std::atomic<int> spareThreads{0};
 
   static constexpr uint32_t kMaxBins = 32;
@@ -196,8 +197,8 @@ struct BlasBuilder
     const float parentArea = halfArea(lo, hi);
     if (n <= maxLeaf)
     {
-      // leaf cost n*A vs split cost 1*A + sum(child area * count)
-      if (bestAxis == 3 || (float)n * parentArea <= parentArea + bestCost)
+      // leaf cost n*A vs split cost Ct*A + sum(child area * count)
+      if (bestAxis == 3 || (float)n * parentArea <= traversalCost * parentArea + bestCost)
         return rtflat_make_leaf(recordBase + b, n);
     }
     uint32_t mid;
@@ -520,6 +521,7 @@ FlatScene flattenScene(const ScenePoolsView& pools, const FlattenOptions& opt)
     bb.nextNode = &nextNode;
     bb.recordBase = recordBase[m];
     bb.maxLeaf = maxLeaf;
+    bb.traversalCost = opt.traversalCost;
     bb.bins = bins;
     bb.spareThreads = (int)threads - 1;
     float lo[3], hi[3];

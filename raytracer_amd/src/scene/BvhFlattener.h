@@ -21,6 +21,9 @@ struct FlattenOptions
   bool referenceEdgeIndexing = true;
   uint32_t maxLeafTriangles = 4; // <= RTFLAT_MAX_LEAF_TRIS
   uint32_t sahBins = 16;
+  // SAH cost of visiting an inner node relative to one triangle test: a run of up to maxLeafTriangles triangles stays a
+  // leaf when n * area <= traversalCost * area + (cost of the best split)
+  float traversalCost = 1.0f;
   float originBoundScale = 4.0f; // ray origins are promised to stay within this many scene diagonals of the centre
   float padUlps = 16.0f;         // box padding in units of 2^-24 * (largest coordinate magnitude a ray can see)
   float cullRel = 1.0f / 4096.0f;

@@ -30,6 +30,9 @@ def main():
         extra["materials"] = 1
     if os.environ.get("RT_PROBE_POINT_SHADOWS"):
         extra["pointShadows"] = 1
+    for kv in filter(None, os.environ.get("RT_PROBE_OPTS", "").split(",")):  # e.g. RT_PROBE_OPTS=maxLeafTriangles=8,deviceBvh=1
+        k, v = kv.split("=")
+        extra[k] = float(v)
     for pipelining in ((0,) if os.environ.get("RT_PROBE_ALONE") else (1, 0)):
         r = spec.build_product(options=dict(maxDepth=depth, pipelining=pipelining, **extra))
         cam = spec.product_camera()
