@@ -231,8 +231,16 @@ def main():
     native_gather = world > 1 and backend == "nccl" and not args.torch_gather and not dynamic
     per_rank_floats = rdist.padded_tile_count(assignment) * ts * ts * 3
     gathered = None
+    gather_note = None
     if native_gather:
-        rdist.init_native_comm(r, dist, rank, world)
+        try:
+            rdist.init_native_comm(r, dist, rank, world)
+        except ra.RtError as e:  # raised on every rank alike: RCCL could not be loaded or joined from the C ABI
+            native_gather = False
+            gather_note = "rthip_gather unavailable (%s): gathered with torch.distributed" % e
+            if rank == 0:
+                print("bench: " + gather_note, file=sys.stderr, flush=True)
+    if native_gather:
         if rank == 0:
             gathered = torch.empty((world, per_rank_floats), dtype=torch.float32, device=dev)
 
@@ -454,7 +462,7 @@ def main():
                       "rays_per_step": int(rays_frame), "primary": int(t[2]), "secondary_extend": int(t[3]), "shadow": int(t[4]),
                       "parallelism": (f"tiles64-{'dynamic' if dynamic else 'rr'}-x{world}-{backend}-{'rthip_gather' if native_gather else 'torch_gather'}"
                                       if world > 1 else "single"),
-                      "balance": balance, "gather_ms": round(float(np.mean(gather_ms)), 4) if gather_ms else None, "frame_check": frame_check},
+                      "balance": balance, "gather_ms": round(float(np.mean(gather_ms)), 4) if gather_ms else None, "gather_note": gather_note, "frame_check": frame_check},
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
     if world > 1:

@@ -83,14 +83,27 @@ def init_native_comm(renderer, dist, rank, world_size):
 
     from . import capi
     hl = capi.hip_lib()
-    box = [None]
-    if rank == 0:
-        buf = C.create_string_buffer(capi.RTHIP_COMM_ID_BYTES)
-        capi._check(hl.rthip_comm_unique_id(buf), "rthip_comm_unique_id")
-        box[0] = buf.raw
+
+    def agreed(ok, what):
+        """True when every rank succeeded; otherwise every rank raises the same way (nobody is left waiting in a collective)."""
+        if world_size > 1:
+            flags = [None] * world_size
+            dist.all_gather_object(flags, (bool(ok), what))
+        else:
+            flags = [(bool(ok), what)]
+        bad = [(k, w) for k, (good, w) in enumerate(flags) if not good]
+        if bad:
+            raise capi.RtError(capi.RTHIP_E_COMM, "rank %d: %s" % bad[0])
+
+    # every rank proves it can load RCCL before anyone enters ncclCommInitRank (a rank that cannot would leave the rest hanging)
+    buf = C.create_string_buffer(capi.RTHIP_COMM_ID_BYTES)
+    rc = hl.rthip_comm_unique_id(buf)
+    agreed(rc == 0, "rthip_comm_unique_id: " + capi.error_string(rc))
+    box = [buf.raw if rank == 0 else None]
     if world_size > 1:
         dist.broadcast_object_list(box, src=0)
-    capi._check(hl.rthip_comm_init(renderer.context, box[0], int(rank), int(world_size)), "rthip_comm_init")
+    rc = hl.rthip_comm_init(renderer.context, box[0], int(rank), int(world_size))
+    agreed(rc == 0, "rthip_comm_init: " + capi.error_string(rc))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
