@@ -120,7 +120,12 @@ def roofline_block(workload, ktimes, wc, spp, ktimes_alone=None, scene_bytes=Non
                              "l2_hit_rate": counters.get("l2_hit_rate")},
             "valu": {"wave_insts_per_launch": valu_insts, "Ginst/s": round(valu_insts / launch_s / 1e9, 1) if valu_insts else None,
                      "peak_Ginst/s": VALU_PEAK_GINST, "frac_of_valu_peak": round(valu_frac, 4) if valu_frac is not None else None,
-                     "lane_utilisation": counters.get("valu_lane_utilisation")},
+                     "lane_utilisation": counters.get("valu_lane_utilisation"),
+                     # SQ_ACTIVE_INST_VALU (quad-cycles a SIMD spends executing VALU instructions) x 4 / SIMD cycles, kernels alone
+                     # under rocprofv3 --pmc: the share of time the vector ALU port is taken.  frac_of_valu_peak prices every
+                     # instruction at the 2 clocks of an fp32 FMA; conversions, integer, select and 3-operand instructions --
+                     # most of a node step -- take 4 (tools/ubench/valu_asm.hip), which this counter sees
+                     "busy_under_pmc": counters.get("valu_busy_under_pmc")},
             "algorithmic_bytes_per_launch": round(alg_bytes[dominant] / max(1e-9, k_launches), 1),
             "avg_launch_ms": round(k_ms / max(1e-9, k_launches), 5), "launches_per_step": round(k_launches, 2),
             "nodes_per_extend_ray": round(wc["nodesVisitedExtend"] / max(1, n_ext), 3),

@@ -77,6 +77,12 @@ def main():
             # profiles/r02_valu_rate.txt, 2 with several waves per SIMD; quarter-rate and IEEE divide / sqrt sequences take
             # longer, so this is a lower bound); GRBM_GUI_ACTIVE is summed over the 8 XCDs
             d["valu_issue_utilisation"] = round(g("SQ_INSTS_VALU") * VALU_CYCLES_PER_INST / (NUM_SIMD * g("GRBM_GUI_ACTIVE") / NUM_XCD), 4)
+        if g("SQ_ACTIVE_INST_VALU") and g("GRBM_GUI_ACTIVE"):
+            # the hardware's own figure: SQ_ACTIVE_INST_VALU counts quad-cycles (4 clocks) a SIMD spends executing VALU
+            # instructions.  Only fp32 add / mul / fma take 2 clocks (tools/ubench/valu_asm.hip: 1.13 ns against 1.81 ns for
+            # conversions, integer, compare / select and three-operand instructions), so for instruction mixes like the
+            # traversal kernels' -- mostly the latter -- this is the fraction of time the vector ALU port is taken
+            d["valu_busy"] = round(g("SQ_ACTIVE_INST_VALU") * 4.0 / (NUM_SIMD * g("GRBM_GUI_ACTIVE") / NUM_XCD), 4)
         out[k] = d
         bk = bench_key(k)
         if bk and "COUNT" not in k:
@@ -99,6 +105,8 @@ def main():
             e["valu_lane_utilisation"] = round(a["SQ_THREAD_CYCLES_VALU"] / (a["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
         if a.get("SQ_INSTS_VALU") and a.get("GRBM_GUI_ACTIVE"):
             e["valu_issue_utilisation_under_pmc"] = round(a["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / (NUM_SIMD * a["GRBM_GUI_ACTIVE"] / NUM_XCD), 4)
+        if a.get("SQ_ACTIVE_INST_VALU") and a.get("GRBM_GUI_ACTIVE"):
+            e["valu_busy_under_pmc"] = round(a["SQ_ACTIVE_INST_VALU"] * 4.0 / (NUM_SIMD * a["GRBM_GUI_ACTIVE"] / NUM_XCD), 4)
         if a.get("SQ_WAVE_CYCLES"):
             for c, name in (("SQ_WAIT_ANY", "wave_time_waiting_on_counters"), ("SQ_WAIT_INST_ANY", "wave_time_waiting_to_issue"),
                             ("SQ_ACTIVE_INST_ANY", "wave_time_issuing")):

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void k(float* out, float seed, unsigned useed)
       }
       if (KIND == 9) a[i] = (float)((u[i] >> 8) & 0xffu) + a[i], u[i] += 0x01010101u; // v_cvt_f32_ubyte1 + add + add
       if (KIND == 10) a[i] = fmaxf(fmaxf(a[i], a[(i + 1) & 7]), a[(i + 3) & 7]) * 0.999f; // v_max3_f32 + mul
+      if (KIND == 12) a[i] = __uint_as_float(__builtin_amdgcn_perm(0x3f800000u, u[i], 0x07060500u + (i & 3))) + a[i], u[i] += 0x01010101u; // v_perm_b32 + add + add
       if (KIND == 11) { const unsigned x = u[i], y = u[(i + 1) & 7]; u[i] = (x < y ? x : y) + 3u; } // v_min_u32 + add
     }
   }
@@ -53,11 +54,11 @@ int main()
   const int blocks = p.multiProcessorCount * 8; // 8 blocks x 4 waves = 32 waves/CU = 8 waves/SIMD
   float* d; hipMalloc(&d, blocks * 256 * sizeof(float));
   const char* names[] = {"fma_f32", "mul_f32", "mul_lo_u32+lshr+add", "rcp+add", "ieee_div+add", "ieee_sqrt+add", "lshr+add+xor", "cmp+cndmask+2add",
-                         "pk_fma_f32 (4 per 8)", "cvt_f32_ubyte+2add", "max3_f32+mul", "min_u32+add"};
-  float ms[12] = {run<0>(d, blocks), run<1>(d, blocks), run<2>(d, blocks), run<3>(d, blocks), run<4>(d, blocks), run<5>(d, blocks), run<6>(d, blocks), run<7>(d, blocks),
-                  run<8>(d, blocks), run<9>(d, blocks), run<10>(d, blocks), run<11>(d, blocks)};
+                         "pk_fma_f32 (4 per 8)", "cvt_f32_ubyte+2add", "max3_f32+mul", "min_u32+add", "perm_b32+2add"};
+  float ms[13] = {run<0>(d, blocks), run<1>(d, blocks), run<2>(d, blocks), run<3>(d, blocks), run<4>(d, blocks), run<5>(d, blocks), run<6>(d, blocks), run<7>(d, blocks),
+                  run<8>(d, blocks), run<9>(d, blocks), run<10>(d, blocks), run<11>(d, blocks), run<12>(d, blocks)};
   // per SIMD: 8 waves x N_ITER x 8 statements
-  for (int i = 0; i < 12; ++i)
+  for (int i = 0; i < 13; ++i)
   {
     const double stmts_per_simd = 8.0 * N_ITER * 8.0;
     printf("%-22s %8.3f ms  -> %.2f ns per wave-statement per SIMD (x clock GHz = cycles; at 2.4 GHz: %.2f cycles)\n", names[i], ms[i], ms[i] * 1e6 / stmts_per_simd,
