@@ -459,6 +459,10 @@ def main():
     if not args.no_cpu_baseline:
         cpu = cpu_baseline(spec, wl, flat, args.cpu_seconds)
 
+    _mode, _cal = r.refill_mode()
+    refill_info = {"mode": "high (coherent rays)" if _mode else "low (incoherent rays)",
+                   "calibration_ms_low_high": [round(float(_cal[0]), 3), round(float(_cal[1]), 3)],
+                   "note": "traversal refill thresholds measured once per scene and frame shape before the warm-up step (rthip_set_refill_mode)"}
     out = {"metric": "Mrays/s (primary+secondary)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
@@ -467,7 +471,8 @@ def main():
                       "rays_per_step": int(rays_frame), "primary": int(t[2]), "secondary_extend": int(t[3]), "shadow": int(t[4]),
                       "parallelism": (f"tiles64-{'dynamic' if dynamic else 'rr'}-x{world}-{backend}-{'rthip_gather' if native_gather else 'torch_gather'}"
                                       if world > 1 else "single"),
-                      "balance": balance, "gather_ms": round(float(np.mean(gather_ms)), 4) if gather_ms else None, "gather_note": gather_note, "frame_check": frame_check},
+                      "balance": balance, "gather_ms": round(float(np.mean(gather_ms)), 4) if gather_ms else None, "gather_note": gather_note, "frame_check": frame_check,
+                      "refill": refill_info},
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
     if world > 1:

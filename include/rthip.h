@@ -118,6 +118,14 @@ int rthip_upload_materials(rthip_ctx* ctx, const rtflat_shade* shade, uint32_t n
  * numDir + numPoint <= 32 (RTHIP_E_LIMIT). */
 int rthip_set_point_shadows(rthip_ctx* ctx, int on);
 
+/* How full a wave must have run before it hands out new rays ("refill rule"): 0 = the low thresholds
+ * that suit incoherent rays, 1 = the high ones that suit coherent rays, -1 (default) = measured: the first rthip_begin after
+ * a scene upload or a change of the frame's shape traces a sample of the frame with either setting (a few milliseconds,
+ * one host synchronisation) and keeps the faster.  Results do not depend on it.  rthip_get_refill_mode reports the setting
+ * in use and the two timings in ms (0 when none was taken). */
+int rthip_set_refill_mode(rthip_ctx* ctx, int mode);
+int rthip_get_refill_mode(rthip_ctx* ctx, int* modeOut, float msOut[2]);
+
 /* Starts a frame: allocates and clears accumulator/image for the tiles of `frame`
  * (CPURenderer::render's prologue, src/cpu/CPURenderer.cpp:140-143). */
 int rthip_begin(rthip_ctx* ctx, const rthip_camera* camera, const rthip_frame_desc* frame);

@@ -115,6 +115,8 @@ def hip_lib():
         L.rthip_upload_materials.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64]
         L.rthip_set_point_shadows.argtypes = [vp, C.c_int]
         L.rthip_begin.argtypes = [vp, C.POINTER(Camera), C.POINTER(FrameDesc)]
+        L.rthip_set_refill_mode.argtypes = [vp, C.c_int]
+        L.rthip_get_refill_mode.argtypes = [vp, C.POINTER(C.c_int), fp]
         _hip = L
     return _hip
 
@@ -447,6 +449,13 @@ class Renderer:
 
         texels = view(tx, 3 * nt.value, np.dtype("<f4")).reshape(-1, 3) if tx.value else np.zeros((0, 3), np.float32)
         return dict(_owner=self, shade=view(sh, n_tris, SHADE_DTYPE), materials=view(mt, nm.value, MATERIAL_DTYPE), texels=texels)
+
+    def refill_mode(self):
+        """(mode in use: 0 low / 1 high refill thresholds, [ms with low, ms with high] of the last calibration)"""
+        m = C.c_int()
+        ms = np.zeros(2, np.float32)
+        _check(hip_lib().rthip_get_refill_mode(self.context, C.byref(m), _fp(ms)), "rthip_get_refill_mode")
+        return int(m.value), ms
 
     def build_times(self):
         """(host seconds of the flattener, device milliseconds of the BVH build -- 0 unless option deviceBvh was set)"""

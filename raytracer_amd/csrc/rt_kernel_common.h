@@ -19,7 +19,8 @@ constexpr uint32_t kLeafTrigger = 4;    // lanes that must be waiting on a leaf 
 constexpr uint32_t kLeafTriggerHi = 24; // ... or takes it regardless (see the leaf-step rule in k_trace)
 constexpr uint32_t kDone = 0xffffffffu; // `cur`: the ray has no node, leaf or model left (== RTFLAT_INVALID)
 constexpr uint32_t kNone = 0xfffffffeu; // `cur` / `postponed`: empty
-constexpr uint32_t kRefillThreshold = 16; // refill once this many lanes are idle (or no lane is active)
+constexpr uint32_t kRefillThreshold = 16; // refill once this many lanes are idle (or no lane is active): incoherent rays
+constexpr uint32_t kRefillCoherent = 56;  // the same for coherent rays, whose lanes finish together (see the refill rule in k_trace)
 constexpr uint32_t kMaxRun = 1024;     // most work items one wave is handed (static mode)
 constexpr uint32_t kShadeRun = 1024;   // items a wave shades between two appends to the next depth's slot list (one atomic per run)
 constexpr uint32_t kFetchShards = 8;   // one work counter per XCD label (blockIdx % 8): 8x the atomic rate of one word, L2-local ranges

@@ -18,7 +18,7 @@ struct TraceArgs
   const uint32_t* listCount; // sparse: number of work items (device memory)
   uint32_t runLen;           // static mode: work items per wave (multiple of 64, <= kMaxRun)
   uint32_t chunkLen;         // dynamic mode: work items per fetch (multiple of 64); 0 = derive it from the list length on the device
-  uint32_t refillAt;         // idle lanes that trigger a refill from the work list
+  uint32_t refillAt;         // idle lanes that trigger a refill from the work list (see the refill rule in the traversal loop)
   uint32_t leafTrigger;      // lanes waiting on a leaf that trigger a leaf step once their number has stopped growing ...
   uint32_t leafTriggerHi;    // ... or at once when this many wait
   uint32_t stealSpans;       // spans a wave may pull chunks from: its own first, then its neighbours'
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 6)) void k_tra
       // so idle lanes are refilled with the next consecutive slots of the chunk once half the wave is idle
       const uint64_t idleMask = __ballot(!active);
       const uint32_t numIdle = __popcll(idleMask);
-      if (numIdle >= 32)
+      if (numIdle >= a.refillAt)
       {
         if (runNext >= runEnd && !exhausted)
           fetchChunk();
@@ -272,9 +272,10 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 6)) void k_tra
       // ---------------- work list: scan + compact the next chunk of the run when the list has run dry
       const uint64_t idleMask = __ballot(!active);
       const uint32_t numIdle = __popcll(idleMask);
-      if (listNext >= listCount && numIdle >= a.refillAt && runNext >= runEnd && !exhausted)
+      const bool refilling = numIdle >= a.refillAt;
+      if (listNext >= listCount && refilling && runNext >= runEnd && !exhausted)
         fetchChunk();
-      if (listNext >= listCount && runNext < runEnd && numIdle >= a.refillAt)
+      if (listNext >= listCount && runNext < runEnd && refilling)
       {
         const uint32_t chunkEnd = min(runEnd, runNext + kChunk);
         uint32_t n = 0;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 6)) void k_tra
       }
       // ---------------- hand list entries to idle lanes (ballot + mbcnt compaction)
       const uint32_t avail = listCount - listNext;
-      if (avail > 0 && (numIdle >= a.refillAt || numIdle == 64))
+      if (avail > 0 && refilling)
       {
         const uint32_t r = rankIn(idleMask);
         const bool take = !active && r < avail;
@@ -354,7 +355,6 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 6)) void k_tra
     const bool refillPossible = (MODE == PRIMARY_GROUP) ? false
                                 : (MODE == PRIMARY)     ? (runNext < runEnd || !exhausted)
                                                         : (listNext < listCount || runNext < runEnd || !exhausted);
-    const uint32_t refillAt = (MODE == PRIMARY) ? 32u : a.refillAt;
     // ---------------- traversal: a wave alternates NODE steps (every lane that holds an inner node tests its two child
     // boxes) with LEAF steps (every lane that holds a postponed leaf runs the reference's triangle test on it).  A lane
     // that reaches a leaf parks it in `postponed` and keeps walking inner nodes; the leaf step is taken only once
@@ -544,8 +544,13 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 6)) void k_tra
       }
       if (nodeMask == 0)
         break; // nothing left to traverse in this wave: back to the work list
-      // leave for a refill as soon as enough lanes are idle and there is work to hand out
-      if (refillPossible && (uint32_t)__popcll(__ballot(!active)) >= refillAt)
+      // Leave for a refill once enough lanes are idle and there is work to hand out.  How many is enough depends on the rays
+      // and is the launch's choice (a.refillAt): coherent ones -- a pixel's samples over a terrain, shadow rays toward one
+      // light -- finish within a few steps of each other, and handing new rays to the first finishers only puts the wave's
+      // lanes out of step for good (hf10m at 64 spp: -10 % frame time with 56 instead of 16, the bunny -11 %); incoherent
+      // ones finish one by one and waiting only idles lanes (1M soup: +20 % with 56, +39 % with whole groups).  The host
+      // measures which way a scene leans (rthip.hip: calibrateRefill).
+      if (refillPossible && (uint32_t)__popcll(__ballot(!active)) >= a.refillAt)
         break;
       // --- NODE step: one 64-byte node = four quantised child boxes
       if (COUNT)

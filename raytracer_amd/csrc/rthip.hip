@@ -195,6 +195,15 @@ struct rthip_ctx
   uint32_t overlapShadow = 1;    // run a depth's shadow and closest-hit launches on two streams (their tails overlap)
   uint32_t tuneSteal = 1; // spans a wave may pull chunks from (1 = its own only; stealing measured +4% on the 1M soup, -4% on the bunny: off)
   uint32_t tuneRefill = kRefillThreshold, tuneLeaf = kLeafTrigger, tuneLeafHi = kLeafTriggerHi;
+  uint32_t tuneRefillShadow = kRefillThreshold, tuneRefillPrimary = 32; // the low thresholds of shadow / dynamic primary launches (RTHIP_TUNE fields 8, 9)
+  uint32_t tuneRefillHi = kRefillCoherent;                              // the high threshold (field 10)
+  // Which refill thresholds the traversal launches use: low (incoherent rays) or high (coherent rays), see k_trace.  -1 in
+  // refillWanted = measure it (calibrateRefill) whenever the scene or the frame's shape changes; 0 / 1 = fixed by the caller.
+  int refillWanted = -1, refillMode = 0;
+  uint64_t refillKey = 0;        // what the current refillMode was measured for
+  uint32_t sceneEpoch = 0;       // counts scene uploads
+  float refillMs[2] = {0, 0};    // the two calibration timings (low, high), for inspection
+  uint32_t calibLog2 = 24;       // paths in the calibration sample (RTHIP_CALIB_LOG2): fewer, and launches are tail-bound, which hides the difference
   bool fusedPrimary = true;      // generate rays inside the depth-0 traversal kernel instead of storing them
   uint32_t lastBatchBegin = 0, lastBatchCount = 0, lastSamp = 0;
   bool renderedAny = false;
@@ -447,7 +456,7 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   a.tmin = tmin;
   a.tmax = tmax;
   a.anyOut = c->anyOut.p;
-  a.refillAt = c->tuneRefill;
+  a.refillAt = c->refillMode ? c->tuneRefillHi : (isShadow(MODE) ? c->tuneRefillShadow : (MODE == PRIMARY ? c->tuneRefillPrimary : c->tuneRefill));
   a.leafTrigger = c->tuneLeaf;
   a.leafTriggerHi = c->tuneLeafHi;
   a.stealSpans = c->tuneSteal;
@@ -488,7 +497,8 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
 // One batch of `count` sample passes starting at sampBegin.  Nothing here waits for the device: from depth 1 on every
 // launch works on the slot list the previous depth's k_shade wrote, whose length stays in device memory, so all depths up
 // to the cap are queued unconditionally (a launch whose list is empty returns at once) and batches and frames can overlap.
-int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, uint32_t tileBegin, uint32_t tileCount, bool fresh, hipEvent_t accumulateAfter = nullptr)
+int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, uint32_t tileBegin, uint32_t tileCount, bool fresh, hipEvent_t accumulateAfter = nullptr,
+                bool calibrating = false)
 {
   const uint32_t P = c->geom.numLocalPixels; // of the frame (AOV arrays are indexed by it)
   const uint32_t perTile = c->geom.tileSize * c->geom.tileSize;
@@ -506,6 +516,10 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, uint32_t tileB
     g.batchLg = lg;
   }
   const uint32_t numSlots = g.batchPixels * count;
+  // every kernel below indexes the path arrays by slot without bounds checks: the batch must fit what rthip_begin sized
+  if ((uint64_t)g.batchPixels * count > std::min<uint64_t>(std::min<uint64_t>(c->rayO.n, c->hit.n), std::min<uint64_t>(c->listA.n, c->listB.n)) ||
+      (c->materialsOn && (uint64_t)g.batchPixels * count > c->alb.n) || tileBegin + tileCount > c->geom.numLocalTiles)
+    return RTHIP_E_LIMIT;
   const uint32_t shadeBlocks = std::max(1u, std::min((numSlots + kShadeRun * kWavesPerBlock - 1) / (kShadeRun * kWavesPerBlock), (uint32_t)c->numCUs * 8u));
   HIPCHK(hipStreamWaitEvent(c->stream, c->evFrame, 0)); // the frame prologue (k_camera) may have run on the other slot's stream
   HIPCHK(hipMemsetAsync(c->fetch.p, 0, c->fetch.n * sizeof(uint32_t), c->stream)); // batch counters + work-fetch counters
@@ -605,6 +619,8 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, uint32_t tileB
     if (last)
       break;
   }
+  if (calibrating) // a timing run (calibrateRefill): the paths are traced and shaded, nothing of them reaches the frame
+    return 0;
   if (accumulateAfter) // the previous batch ran on the other slot: per-pixel accumulation stays in sample order
     HIPCHK(hipStreamWaitEvent(c->stream, accumulateAfter, 0));
   {
@@ -645,6 +661,71 @@ BatchPlan planBatches(const rthip_ctx* c, uint32_t count, const FrameGeom& g, ui
   if (pipelined && bp.tiles == g.numLocalTiles && bp.samples == count && g.numLocalTiles >= 2 && perTile * g.numLocalTiles * count >= (1ull << 23))
     bp.tiles = (g.numLocalTiles + 1) / 2;
   return bp;
+}
+
+// Decides between the low and the high refill thresholds of the traversal launches (k_trace: how many lanes must be idle
+// before a wave hands out new rays) by measuring: a sample of the frame -- a run of tiles from the middle of the local
+// tile list, the sample passes one call would bring, about 16M paths (as far as the path buffers allow) -- is traced three times on the main slot (once to warm
+// the caches, then with either setting) and timed with HIP events.  Nothing of it reaches the accumulator, the AOVs or the
+// counters.  Called by rthip_begin when the scene or the frame's shape has changed since the last measurement; costs a few
+// milliseconds and one synchronisation, then frames queue without waiting as before.
+int calibrateRefill(rthip_ctx* c)
+{
+  const uint64_t key = ((uint64_t)c->sceneEpoch << 48) ^ ((uint64_t)c->geom.width << 32) ^ ((uint64_t)c->geom.height << 16) ^ ((uint64_t)c->geom.numSamples << 8) ^
+                       ((uint64_t)c->maxDepth << 2) ^ ((uint64_t)c->geom.numLocalTiles * 0x9E3779B97F4A7C15ull);
+  if (c->refillWanted >= 0)
+  {
+    c->refillMode = c->refillWanted;
+    return 0;
+  }
+  if (c->aovDepths)
+  {
+    c->refillMode = 0; // AOV frames are parity runs: no timing runs between them
+    return 0;
+  }
+  if (key == c->refillKey)
+    return 0;
+  const uint32_t perTile = c->geom.tileSize * c->geom.tileSize;
+  const uint32_t samples = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(c->geom.numSamples, 64u), c->pathCap / perTile));
+  const uint64_t wantTiles = std::max<uint64_t>(1, (1ull << c->calibLog2) / ((uint64_t)perTile * samples));
+  // never more slots than the path buffers were sized for (rthip_begin: the widest batch a render call of this frame makes)
+  const uint64_t slotCap = std::min<uint64_t>(std::min<uint64_t>(c->rayO.n, c->listA.n), std::min<uint64_t>(c->hit.n, c->pathCap));
+  const uint32_t tiles = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(wantTiles, c->geom.numLocalTiles), slotCap / ((uint64_t)perTile * samples));
+  if (tiles == 0)
+  {
+    c->refillMode = 0;
+    return 0;
+  }
+  const uint32_t first = (c->geom.numLocalTiles - tiles) / 2;
+  const uint32_t keepBegin = c->lastBatchBegin, keepCount = c->lastBatchCount, keepSamp = c->lastSamp;
+  const bool keepRendered = c->renderedAny, keepTiming = c->kernelTiming;
+  c->kernelTiming = false;
+  float ms[2] = {0, 0};
+  int rc = 0;
+  for (int run = 0; run < 3 && !rc; ++run)
+  {
+    c->refillMode = run == 2 ? 1 : 0;
+    rc = (int)hipEventRecord(c->evA, c->stream);
+    if (!rc)
+      rc = renderBatch(c, 0, samples, first, tiles, false, nullptr, true);
+    if (!rc)
+      rc = (int)hipEventRecord(c->evB, c->stream);
+    if (!rc)
+      rc = (int)hipEventSynchronize(c->evB);
+    if (!rc && run > 0)
+      rc = (int)hipEventElapsedTime(&ms[run - 1], c->evA, c->evB);
+  }
+  c->kernelTiming = keepTiming;
+  c->lastBatchBegin = keepBegin, c->lastBatchCount = keepCount, c->lastSamp = keepSamp, c->renderedAny = keepRendered;
+  if (rc)
+  {
+    c->refillMode = 0;
+    return rc;
+  }
+  c->refillMs[0] = ms[0], c->refillMs[1] = ms[1];
+  c->refillMode = ms[1] < 0.98f * ms[0] ? 1 : 0; // the high thresholds must win by more than the noise of the measurement
+  c->refillKey = key;
+  return 0;
 }
 
 int renderPasses(rthip_ctx* c, uint32_t sampBegin, uint32_t count, bool sync)
@@ -741,8 +822,15 @@ static int createContext(rthip_ctx* c, int device)
   c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* t = getenv("RTHIP_TUNE")) // "refill,leaf[,blocksPerCU]" -- tuning experiments only
   {
-    unsigned r = 0, l = 0, b = 0, st = 1, ov = 1, pl = 1, lh = 0;
-    const int n = sscanf(t, "%u,%u,%u,%u,%u,%u,%u", &r, &l, &b, &st, &ov, &pl, &lh);
+    unsigned r = 0, l = 0, b = 0, st = 1, ov = 1, pl = 1, lh = 0, rs = 0, rp = 0, rh = 0, pa = 0;
+    const int n = sscanf(t, "%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u", &r, &l, &b, &st, &ov, &pl, &lh, &rs, &rp, &rh, &pa);
+    if (n >= 10 && rh >= 1 && rh <= 64)
+      c->tuneRefillHi = rh;
+    (void)pa;
+    if (n >= 8 && rs >= 1 && rs <= 64)
+      c->tuneRefillShadow = rs;
+    if (n >= 9 && rp >= 1 && rp <= 64)
+      c->tuneRefillPrimary = rp;
     if (n >= 7 && lh >= 1 && lh <= 64)
       c->tuneLeafHi = lh;
     if (n >= 2 && r >= 1 && r <= 64 && l >= 1 && l <= 64)
@@ -762,6 +850,10 @@ static int createContext(rthip_ctx* c, int device)
     if (v >= 16 && v <= 30)
       c->pathCap = 1ull << v;
   }
+  if (const char* t = getenv("RTHIP_CALIB_LOG2"))
+    c->calibLog2 = (uint32_t)std::max(16, std::min(27, atoi(t)));
+  if (const char* t = getenv("RTHIP_REFILL_MODE")) // 0 / 1: fixed low / high refill thresholds instead of the measured choice
+    c->refillWanted = atoi(t) ? 1 : 0;
   if (const char* t = getenv("RTHIP_GROUP_LG"))
     c->groupLg = atoi(t);
   c->traceBlocks = (uint32_t)c->numCUs * c->tuneBlocks; // 6 blocks x 4 waves = 24 waves per CU: what 24 KB of LDS per block admits
@@ -914,6 +1006,7 @@ int rthip_upload_scene(rthip_ctx* c, const rtflat_info* info, const rtflat_model
   c->spill.release(); // sized per scene in ensurePathBuffers
   c->alt.spill.release();
   c->materialsOn = false; // they described the previous scene's triangles
+  c->sceneEpoch++;
   c->haveScene = true;
   c->haveFrame = false;
   return 0;
@@ -1080,6 +1173,7 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
   c->spillCap = 3 * deepest + 2 > kStackLds ? 3 * deepest + 2 - kStackLds : 1u;
   c->spill.release(); // sized per scene in ensurePathBuffers
   c->alt.spill.release();
+  c->sceneEpoch++;
   c->haveScene = true;
   return 0;
 }
@@ -1288,6 +1382,26 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
     c->altPending = true;
   c->renderedAny = false;
   c->haveFrame = true;
+  return calibrateRefill(c); // a no-op unless the scene or the frame's shape changed since the last measurement
+}
+
+int rthip_set_refill_mode(rthip_ctx* c, int mode)
+{
+  if (!c || mode < -1 || mode > 1)
+    return RTHIP_E_ARG;
+  c->refillWanted = mode;
+  c->refillKey = 0; // (back to -1: measure again at the next rthip_begin)
+  return 0;
+}
+
+int rthip_get_refill_mode(rthip_ctx* c, int* modeOut, float msOut[2])
+{
+  if (!c)
+    return RTHIP_E_ARG;
+  if (modeOut)
+    *modeOut = c->refillMode;
+  if (msOut)
+    msOut[0] = c->refillMs[0], msOut[1] = c->refillMs[1];
   return 0;
 }
 

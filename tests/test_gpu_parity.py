@@ -420,3 +420,32 @@ def test_gather_over_rccl_single_rank_communicator():
     assert hl.rthip_comm_destroy(r.context) == 0
     assert hl.rthip_gather(r.context, recv.data_ptr(), per_rank, 0) == ra.capi.RTHIP_E_STATE
     r.close()
+
+
+@pytest.mark.parametrize("W,H,N", [(96, 64, 1), (640, 360, 4), (300, 200, 70), (1920, 1080, 2)])
+def test_refill_modes_render_the_same_bits_and_calibration_stays_inside_the_buffers(W, H, N):
+    """The refill thresholds of the traversal launches (rthip_set_refill_mode) are a matter of speed only: low, high and the
+    measured choice give the same accumulator.  The measuring run traces a sample of the frame before the first pass; frame
+    shapes whose whole frame is smaller than that sample, or whose batches are cut in two for the two slots, must keep it
+    within what rthip_begin allocated (it once did not)."""
+    spec = scenes.heightfield_scene(64)
+    frames = {}
+    for mode in (0, 1, -1):
+        r = spec.build_product(options=dict(maxDepth=5, refillMode=mode))
+        r.begin_frame(spec.product_camera(), W, H, N)
+        got, ms = r.refill_mode()
+        if mode >= 0:
+            assert got == mode and not ms.any()
+        else:
+            assert got in (0, 1) and (ms > 0).all(), "the first frame of a scene measures both settings"
+        r.render_passes(0, N)
+        frames[mode] = r.accumulator()
+        if mode < 0:
+            r.begin_frame(spec.product_camera(), W, H, N)  # same scene, same shape: no second measurement
+            assert np.array_equal(r.refill_mode()[1], ms)
+            r.render_passes(0, N)
+            assert np.array_equal(r.accumulator().view(np.uint32), frames[mode].view(np.uint32))
+        r.close()
+    assert frames[0].any()
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+    assert np.array_equal(frames[0].view(np.uint32), frames[-1].view(np.uint32))

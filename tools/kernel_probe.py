@@ -16,6 +16,7 @@ def main():
     spec = wl["spec"]()
     W, H, N, depth = wl["width"], wl["height"], wl["spp"], wl["max_depth"]
     import os
+    N = int(os.environ.get("RT_PROBE_SPP", N))
     extra = {}
     if os.environ.get("RT_PROBE_MATERIALS"):
         import numpy as np
@@ -45,7 +46,9 @@ def main():
             ms = (time.perf_counter() - t) * 1e3 / frames
         c = r.counters()
         rays = c["extendPrimary"] + c["extendSecondary"] + c["shadow"]
-        print("%s pipelining=%d: %.3f ms per frame, %.1f Mrays/s" % (name, pipelining, ms, rays / ms / 1e3), flush=True)
+        mode, cal = r.refill_mode()
+        print("%s pipelining=%d: %.3f ms per frame, %.1f Mrays/s   (refill mode %d, calibration low/high %.3f / %.3f ms)" % (
+            name, pipelining, ms, rays / ms / 1e3, mode, cal[0], cal[1]), flush=True)
         if not pipelining:
             r.set_option("kernelTiming", 1)
             r.begin_frame(cam, W, H, N)
