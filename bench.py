@@ -460,9 +460,9 @@ def main():
         cpu = cpu_baseline(spec, wl, flat, args.cpu_seconds)
 
     _mode, _cal = r.refill_mode()
-    refill_info = {"mode": "high (coherent rays)" if _mode else "low (incoherent rays)",
-                   "calibration_ms_low_high": [round(float(_cal[0]), 3), round(float(_cal[1]), 3)],
-                   "note": "traversal refill thresholds measured once per scene and frame shape before the warm-up step (rthip_set_refill_mode)"}
+    refill_info = {"mode": ("low refill thresholds (incoherent rays)", "high refill thresholds (coherent rays)", "packet traversal of camera and shadow rays")[_mode],
+                   "calibration_ms_low_high_packet": [round(float(v), 3) for v in _cal],
+                   "note": "how a wave treats its 64 rays, measured once per scene and frame shape before the warm-up step (rthip_set_refill_mode)"}
     out = {"metric": "Mrays/s (primary+secondary)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",

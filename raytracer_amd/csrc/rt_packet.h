@@ -1,0 +1,370 @@
+// rt_packet.h: packet traversal -- a wave walks the tree ONCE for its 64 rays -- part of the gfx950 kernel library (see rthip.hip for the pipeline overview and DESIGN.md section 5).
+#pragma once
+#include "rt_trace.h"
+
+namespace rtk
+{
+// Wave-uniform loads: one scalar load brings a whole 64-byte record (node, triangle, model node) into 16 SGPRs -- one request
+// per wave into the scalar cache instead of 64 lanes asking the vector memory path for the same line.  Written as inline
+// assembly because the compiler only selects scalar loads where it can prove that no store of the kernel may alias, which
+// it cannot here; the scene arrays are written by no kernel.  (Loads only: nothing is ever written through the scalar cache.)
+typedef int record16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ record16 loadRecord(const void* p)
+{
+  record16 r;
+  asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ float4 recordQuarter(const record16& r, int q)
+{
+  return make_float4(__int_as_float(r[4 * q]), __int_as_float(r[4 * q + 1]), __int_as_float(r[4 * q + 2]), __int_as_float(r[4 * q + 3]));
+}
+
+// A wave-wide stack held in one VGPR per word: entry i lives in lane i (v_writelane / v_readlane), so a push or a pop is one
+// instruction per word, costs no LDS and -- unlike the per-lane stacks of k_trace -- is shared by the 64 rays.
+__device__ __forceinline__ void laneStackWrite(uint32_t& reg, uint32_t value, uint32_t index)
+{
+  // (two different SGPR operands would break the constant-bus limit, so the lane select goes through M0, which is put back)
+  uint32_t keepM0;
+  asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+               : "+v"(reg), "=&s"(keepM0)
+               : "s"(__builtin_amdgcn_readfirstlane(value)), "s"(__builtin_amdgcn_readfirstlane(index)));
+}
+__device__ __forceinline__ uint32_t laneStackRead(uint32_t reg, uint32_t index) { return (uint32_t)__builtin_amdgcn_readlane((int)reg, (int)index); }
+constexpr uint32_t kPacketStack = 64; // entries of the wave stack: the host only picks this kernel when 3 * (BVH depth) fits
+
+// k_trace for COHERENT rays (MODE = PRIMARY: camera rays, generated here; SHADOW: any-hit toward every directional light
+// from the stored origins).  The 64 work items of a group -- with 64 samples per pixel, one pixel's samples -- are traced
+// together: the wave visits one node at a time, every lane tests ITS ray against the node's four child boxes, a child is
+// entered when any lane hits it (the lanes that do are remembered in a 64-bit mask pushed with the reference), and a leaf's
+// triangles are tested by the lanes that reached it.  Node and triangle records are fetched once per wave by scalar loads,
+// the stack is wave-uniform, and there is no per-lane control flow besides the masks, so a node visit costs about a third
+// of k_trace's instructions -- as long as the rays really do go the same way; the host measures that (calibrateRefill).
+//
+// Every lane still applies exactly the tests k_trace applies to its own ray: the reference's slab test on the model boxes
+// (and only the triangles of models whose box chain ITS ray passes), the conservative quantised-box test with its own
+// culling distance, the reference's triangle test, the orderKey tie rule.  A lane may meet triangles in a different order
+// than in k_trace and skip or visit different subtrees, but closest hits are an arg-min with a total tie order and any-hits
+// an OR, so the results are the same bits.
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
+{
+  static_assert(MODE == PRIMARY || MODE == SHADOW, "packet traversal serves camera rays and directional shadow rays");
+  constexpr bool kClosest = MODE == PRIMARY;
+  const uint32_t lane = laneId();
+  const rtflat_model_node* __restrict__ modelNodes = a.scene.modelNodes;
+  const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(a.scene.nodes);
+  const float4* __restrict__ tris4 = reinterpret_cast<const float4*>(a.scene.tris);
+  const uint32_t numModelNodes = a.scene.numModelNodes;
+
+  const bool sparse = a.list != nullptr;
+  const uint32_t total = sparse ? *a.listCount : a.numSlots;
+  // work distribution as in k_trace's dynamic mode: kFetchShards contiguous spans (one per XCD label), chunks of whole groups
+  const uint32_t shard = blockIdx.x % kFetchShards;
+  const uint32_t waves = gridDim.x * kWavesPerBlock;
+  const uint32_t chunkLen = max(64u, min((((total + waves * 8u - 1) / (waves * 8u)) + 63u) & ~63u, 2048u));
+  const uint32_t chunksPerShard = ((total + kFetchShards - 1) / kFetchShards + chunkLen - 1) / chunkLen;
+  uint32_t shardsDone = 0;
+  uint32_t nRays = 0, nNodes = 0, nTris = 0, nNodeSteps = 0, nLeafSteps = 0;
+  uint32_t stackRef = 0, stackLo = 0, stackHi = 0; // the wave stack (see laneStackWrite)
+
+  while (shardsDone < kFetchShards)
+  {
+    const uint32_t sh = (shard + shardsDone) % kFetchShards;
+    uint32_t c = 0;
+    if (lane == 0)
+      c = atomicAdd(a.fetch + sh * kFetchStride, 1u);
+    c = __builtin_amdgcn_readfirstlane(c);
+    const uint32_t chunkBegin = (sh * chunksPerShard + c) * chunkLen;
+    if (!(c < chunksPerShard && chunkBegin < total))
+    {
+      shardsDone++; // this span is empty: help with the next one
+      continue;
+    }
+    const uint32_t chunkEnd = min(total, chunkBegin + chunkLen);
+    for (uint32_t groupBegin = chunkBegin; groupBegin < chunkEnd; groupBegin += 64)
+    {
+      // ---------------- the group's rays
+      const uint32_t item = groupBegin + lane;
+      bool valid = item < chunkEnd;
+      uint32_t slot = item;
+      if (sparse && valid)
+        slot = a.list[item];
+      vec3 o{0, 0, 0}, d{0, 0, 1};
+      float prevNx = 0.0f;
+      if (MODE == PRIMARY)
+      {
+        if (valid)
+        {
+          uint32_t sidx, i, w, h;
+          sampleOf(a.geom, slot, sidx, i);
+          if (!pixelOf(a.geom, i, w, h))
+          {
+            a.pb.live[slot] = kDeadZero; // padding pixel of a tile that overhangs the image
+            valid = false;
+          }
+          else
+          {
+            const uint32_t samp = a.sampBegin + sidx;
+            rtd::primaryRay(*a.cam, a.geom.width, a.geom.height, w, h, samp, rtd::rand01(w, h, samp), o, d);
+          }
+        }
+      }
+      else if (valid)
+      {
+        const float4 ro = a.pb.rayO[slot];
+        o = vec3{ro.x, ro.y, ro.z};
+        prevNx = ro.w;
+      }
+      uint32_t occluded = 0;
+      float best = FLT_MAX;
+      uint32_t bestRec = RTFLAT_INVALID;
+      const uint32_t numPasses = MODE == PRIMARY ? 1u : a.lights->numDir;
+      for (uint32_t pass = 0; pass < numPasses; ++pass)
+      {
+        if (MODE == SHADOW)
+        {
+          const rthip_dir_light& L = a.lights->dir[pass];
+          d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]}; // Ray(position, -d.direction), CPUScene.cpp:34
+        }
+        if (valid)
+          nRays++;
+        const vec3 invD = rtd::padInvDir(d);
+        const vec3 oi = o * invD;
+        // AABB.h:49 divides by the direction: invD is that quotient unless it was clamped (axis-parallel rays)
+        vec3 invRef = invD;
+        if (fabsf(invD.x) == 1e18f || fabsf(invD.y) == 1e18f || fabsf(invD.z) == 1e18f)
+          invRef = rt::rcp3(d);
+        float cull = FLT_MAX;
+        best = FLT_MAX;
+        bestRec = RTFLAT_INVALID;
+        bool live = valid; // this lane's ray is still looking (an any-hit ray stops at its first accepted triangle)
+
+        // ---------------- model tree, pre-order, the whole wave at one node; a lane is inside node mk iff mk >= skipUntil
+        uint32_t skipUntil = 0;
+        for (uint32_t mk = 0; mk < numModelNodes;)
+        {
+          // rtflat_model_node: lo[3] hi[3] left right blas triCount indicesOffset orderBase modelIndex subtreeSize pad[2]
+          const record16 mn = loadRecord(modelNodes + mk);
+          const uint32_t subtree = (uint32_t)mn[13], triCount = (uint32_t)mn[9];
+          bool passed = false;
+          if (live && mk >= skipUntil)
+          {
+            if (COUNT)
+              nNodes++;
+            const float lo[3] = {__int_as_float(mn[0]), __int_as_float(mn[1]), __int_as_float(mn[2])};
+            const float hi[3] = {__int_as_float(mn[3]), __int_as_float(mn[4]), __int_as_float(mn[5])};
+            passed = rtd::refSlab(lo, hi, o, invRef, a.tmin, a.tmax); // CPUScene.cpp:109 / :125, the caller's tmin / tmax
+            if (!passed)
+              skipUntil = mk + subtree;
+          }
+          const uint64_t inside = __ballot(passed);
+          if (inside == 0)
+          {
+            mk += subtree; // no ray of the wave goes in
+            continue;
+          }
+          mk++;
+          if (triCount == 0)
+            continue;
+          // ---------------- the model's triangle BVH
+          uint32_t sp = 0;
+          uint32_t cur = (uint32_t)mn[8];
+          uint64_t curMask = inside;
+          for (;;)
+          {
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            const bool mine = live && ((curMask >> lane) & 1ull);
+            if (rtflat_is_leaf(cur))
+            {
+              if (COUNT)
+                nLeafSteps++;
+              const uint32_t first = rtflat_leaf_first(cur), count = rtflat_leaf_count(cur);
+              for (uint32_t k = 0; k < count; ++k)
+              {
+                const record16 tr = loadRecord(tris4 + (size_t)(first + k) * 4);
+                const float4 a0 = recordQuarter(tr, 0), a1 = recordQuarter(tr, 1), a2 = recordQuarter(tr, 2);
+                if (mine && live)
+                {
+                  if (COUNT)
+                    nTris++;
+                  float t;
+                  const int acc = rtd::triangleTest(vec3{a0.x, a0.y, a0.z}, vec3{a0.w, a1.x, a1.y}, vec3{a1.z, a1.w, a2.x}, o, d, a.tmin, a.tmax, t);
+                  if (acc == 2)
+                    atomicAdd(&a.counters->nonFinite, 1ull);
+                  if (acc == 1)
+                  {
+                    if (kClosest)
+                    {
+                      bool better = t < best;
+                      if (!better && t == best)
+                      {
+                        // tie: the triangle later in (DFS model order, index in model) wins (CPUScene.cpp:231, :136)
+                        const uint32_t keyNew = (uint32_t)tr[13], keyOld = a.scene.tris[bestRec].orderKey;
+                        better = keyNew > keyOld;
+                      }
+                      if (better)
+                      {
+                        best = t;
+                        bestRec = first + k;
+                        cull = rt::fma(best, 1.0f + a.scene.cullRel, a.scene.cullAbs);
+                      }
+                    }
+                    else
+                      live = false; // first accepted triangle ends an any-hit ray (testModel returns true, CPUScene.cpp:182)
+                  }
+                }
+              }
+              if (!kClosest && __ballot(live) == 0)
+                break; // every ray of the wave is occluded
+            }
+            else
+            {
+              if (COUNT)
+                nNodeSteps++;
+              const record16 nd = loadRecord(nodes4 + (size_t)cur * 4);
+              const float4 w0 = recordQuarter(nd, 0), w2 = recordQuarter(nd, 2), w3 = recordQuarter(nd, 3);
+              bool h0 = false, h1 = false, h2 = false, h3 = false;
+              float en0 = 0, en1 = 0, en2 = 0, en3 = 0;
+              if (mine)
+              {
+                if (COUNT)
+                  nNodes++;
+                const rtd::WideNode wn = rtd::wideNodeSetup(w0, w2, w3, invD, oi);
+                float ex0, ex1, ex2, ex3;
+                rtd::wideSlabPair<0>(wn, en0, ex0, en1, ex1);
+                rtd::wideSlabPair<2>(wn, en2, ex2, en3, ex3);
+                h0 = en0 <= ex0 && (!kClosest || en0 <= cull); // unused slots have inverted boxes
+                h1 = en1 <= ex1 && (!kClosest || en1 <= cull);
+                h2 = en2 <= ex2 && (!kClosest || en2 <= cull);
+                h3 = en3 <= ex3 && (!kClosest || en3 <= cull);
+              }
+              uint64_t m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+              // children in the order of their entry distance along the first ray that hits each (any ray would do: the order
+              // only decides how soon the culling distances shrink)
+              uint32_t k0 = m0 ? (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(en0), (int)__builtin_ctzll(m0)) : 0xffffffffu;
+              uint32_t k1 = m1 ? (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(en1), (int)__builtin_ctzll(m1)) : 0xffffffffu;
+              uint32_t k2 = m2 ? (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(en2), (int)__builtin_ctzll(m2)) : 0xffffffffu;
+              uint32_t k3 = m3 ? (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(en3), (int)__builtin_ctzll(m3)) : 0xffffffffu;
+              uint32_t r0 = (uint32_t)nd[4], r1 = (uint32_t)nd[5], r2 = (uint32_t)nd[6], r3 = (uint32_t)nd[7];
+              auto order = [](uint32_t& ka, uint32_t& ra, uint64_t& ma, uint32_t& kb, uint32_t& rb, uint64_t& mb) {
+                if (kb < ka)
+                {
+                  const uint32_t tk = ka, tr = ra;
+                  const uint64_t tm = ma;
+                  ka = kb, ra = rb, ma = mb;
+                  kb = tk, rb = tr, mb = tm;
+                }
+              };
+              order(k0, r0, m0, k1, r1, m1);
+              order(k2, r2, m2, k3, r3, m3);
+              order(k0, r0, m0, k2, r2, m2);
+              order(k1, r1, m1, k3, r3, m3);
+              order(k1, r1, m1, k2, r2, m2);
+              // the farther ones go on the stack, farthest first
+              if (k3 != 0xffffffffu)
+              {
+                laneStackWrite(stackRef, r3, sp), laneStackWrite(stackLo, (uint32_t)m3, sp), laneStackWrite(stackHi, (uint32_t)(m3 >> 32), sp);
+                sp++;
+              }
+              if (k2 != 0xffffffffu)
+              {
+                laneStackWrite(stackRef, r2, sp), laneStackWrite(stackLo, (uint32_t)m2, sp), laneStackWrite(stackHi, (uint32_t)(m2 >> 32), sp);
+                sp++;
+              }
+              if (k1 != 0xffffffffu)
+              {
+                laneStackWrite(stackRef, r1, sp), laneStackWrite(stackLo, (uint32_t)m1, sp), laneStackWrite(stackHi, (uint32_t)(m1 >> 32), sp);
+                sp++;
+              }
+              if (k0 != 0xffffffffu)
+              {
+                cur = r0;
+                curMask = m0;
+                continue;
+              }
+            }
+            if (sp == 0)
+              break;
+            sp--;
+            cur = laneStackRead(stackRef, sp);
+            curMask = (uint64_t)laneStackRead(stackLo, sp) | ((uint64_t)laneStackRead(stackHi, sp) << 32);
+          }
+          if (!kClosest && __ballot(live) == 0)
+            break;
+        }
+        if (MODE == SHADOW && valid && !live)
+          occluded |= 1u << pass;
+      }
+
+      // ---------------- results, as k_trace writes them
+      if (valid)
+      {
+        if (MODE == PRIMARY)
+        {
+          // a primary miss contributes exactly +0: its slot is marked finished here and costs the shade kernel nothing
+          const bool hitSomething = bestRec != RTFLAT_INVALID;
+          if (hitSomething)
+            a.pb.hit[slot] = make_uint2(__float_as_uint(best), bestRec);
+          a.pb.live[slot] = hitSomething ? (uint8_t)0 : kDeadZero;
+        }
+        else if (a.foldFinal)
+        {
+          // last depth: fold the lights into the radiance and finish the path here (same function as k_shade: same bits)
+          const float4 s0 = a.pb.s0[slot];
+          vec3 albedo = referenceAlbedo();
+          if (a.scene.materialsOn)
+          {
+            const float4 al = a.pb.alb[slot];
+            albedo = vec3{al.x, al.y, al.z};
+          }
+          const vec3 radiance = foldLights(a.lights, occluded, o, vec3{prevNx, s0.w, a.pb.nz[slot]}, vec3{s0.x, s0.y, s0.z}, albedo, a.scene.pointShadows);
+          if (a.depth - 1 < a.aovDepths)
+          {
+            uint32_t sidx, i;
+            sampleOf(a.geom, slot, sidx, i);
+            a.aovShadow[((size_t)sidx * a.aovDepths + (a.depth - 1)) * a.geom.numLocalPixels + i] = (uint8_t)occluded;
+          }
+          a.pb.s0[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+          a.pb.live[slot] = kDead;
+        }
+        else
+          a.pb.mask[slot] = occluded;
+      }
+    }
+  }
+
+  // ---------------- tallies: one atomic per wave and counter
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    nRays += __shfl_down(nRays, off);
+    if (COUNT)
+    {
+      nNodes += __shfl_down(nNodes, off);
+      nTris += __shfl_down(nTris, off);
+    }
+  }
+  if (lane == 0)
+  {
+    if (nRays)
+      atomicAdd(MODE == SHADOW ? &a.counters->shadow : &a.counters->extendPrimary, (unsigned long long)nRays);
+    if (COUNT)
+    {
+      atomicAdd(&a.counters->waveNodeSteps, (unsigned long long)nNodeSteps);
+      atomicAdd(&a.counters->waveLeafSteps, (unsigned long long)nLeafSteps);
+      if (nNodes)
+      {
+        atomicAdd(&a.counters->nodesVisited, (unsigned long long)nNodes);
+        if (kClosest)
+          atomicAdd(&a.counters->nodesExtend, (unsigned long long)nNodes);
+      }
+      if (nTris)
+      {
+        atomicAdd(&a.counters->trisTested, (unsigned long long)nTris);
+        if (kClosest)
+          atomicAdd(&a.counters->trisExtend, (unsigned long long)nTris);
+      }
+    }
+  }
+}
+} // namespace rtk

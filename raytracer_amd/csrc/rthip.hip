@@ -51,6 +51,7 @@ using rtd::CameraConsts;
 #include "rt_probes.h"
 #include "rt_shade.h"
 #include "rt_trace.h"
+#include "rt_packet.h"
 
 using namespace rtk;
 
@@ -202,7 +203,7 @@ struct rthip_ctx
   int refillWanted = -1, refillMode = 0;
   uint64_t refillKey = 0;        // what the current refillMode was measured for
   uint32_t sceneEpoch = 0;       // counts scene uploads
-  float refillMs[2] = {0, 0};    // the two calibration timings (low, high), for inspection
+  float refillMs[3] = {0, 0, 0}; // the calibration timings (low, high, packets), for inspection
   uint32_t calibLog2 = 24;       // paths in the calibration sample (RTHIP_CALIB_LOG2): fewer, and launches are tail-bound, which hides the difference
   bool fusedPrimary = true;      // generate rays inside the depth-0 traversal kernel instead of storing them
   uint32_t lastBatchBegin = 0, lastBatchCount = 0, lastSamp = 0;
@@ -456,7 +457,7 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   a.tmin = tmin;
   a.tmax = tmax;
   a.anyOut = c->anyOut.p;
-  a.refillAt = c->refillMode ? c->tuneRefillHi : (isShadow(MODE) ? c->tuneRefillShadow : (MODE == PRIMARY ? c->tuneRefillPrimary : c->tuneRefill));
+  a.refillAt = c->refillMode >= 1 ? c->tuneRefillHi : (isShadow(MODE) ? c->tuneRefillShadow : (MODE == PRIMARY ? c->tuneRefillPrimary : c->tuneRefill));
   a.leafTrigger = c->tuneLeaf;
   a.leafTriggerHi = c->tuneLeafHi;
   a.stealSpans = c->tuneSteal;
@@ -491,6 +492,44 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
     hipLaunchKernelGGL((k_trace<MODE, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
   else
     hipLaunchKernelGGL((k_trace<MODE, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+// packet traversal needs its wave stack (64 entries, up to 3 pushes per level) to hold the deepest chain of the uploaded BVH
+bool packetsPossible(const rthip_ctx* c) { return 3u * c->info.maxDepthBlas + 2u <= kPacketStack; }
+
+// the packet kernel (rt_packet.h) in place of k_trace<PRIMARY> / k_trace<SHADOW>: same arguments, same results
+template <int MODE>
+int launchTracePacket(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBegin, float tmin, float tmax, const uint32_t* list, bool foldFinal, bool sideStream,
+                      const FrameGeom* batchGeom)
+{
+  TraceArgs a{};
+  a.scene = devScene(c);
+  a.pb = pathBuffers(c);
+  a.lights = c->lights.p;
+  a.geom = batchGeom ? *batchGeom : c->geom;
+  a.cam = frameCamera(c);
+  a.sampBegin = sampBegin;
+  a.numSlots = numSlots;
+  a.list = list;
+  a.listCount = list ? &batchCounters(c)->listCount[depth] : nullptr;
+  a.depth = depth;
+  a.counters = batchCounters(c);
+  a.tmin = tmin;
+  a.tmax = tmax;
+  a.foldFinal = foldFinal ? 1u : 0u;
+  a.aovDepths = c->aovDepths;
+  a.aovShadow = c->aovShadow.p;
+  if (c->fetchCursor >= kMaxTraceLaunches)
+    return RTHIP_E_LIMIT;
+  a.fetch = fetchBase(c) + (size_t)(c->fetchCursor++) * kFetchShards * kFetchStride;
+  const uint32_t blocks = (uint32_t)c->numCUs * 8u; // 8 blocks x 4 waves: the kernel keeps within 64 VGPRs and uses no LDS
+  hipStream_t stream = sideStream ? c->stream2 : c->stream;
+  KernelTimer kt(c, isClosest(MODE) ? 1 : 3, stream);
+  if (c->countWork)
+    hipLaunchKernelGGL((k_trace_packet<MODE, true>), dim3(blocks), dim3(kBlock), 0, stream, a);
+  else
+    hipLaunchKernelGGL((k_trace_packet<MODE, false>), dim3(blocks), dim3(kBlock), 0, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -572,8 +611,10 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, uint32_t tileB
       HIPCHK(hipEventRecord(c->evFork, c->stream));
       HIPCHK(hipStreamWaitEvent(c->stream2, c->evFork, 0));
     }
+    const bool packets = c->refillMode == 2 && packetsPossible(c);
     if (d > 0 && haveDirLights &&
         (rc = shadowPoints ? launchTrace<SHADOW_PT>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g)
+             : (packets && d == 1) ? launchTracePacket<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g) // the camera rays' hits: still one pixel per wave
                            : launchTrace<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g)))
       return rc;
     if (side)
@@ -588,6 +629,8 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, uint32_t tileB
       // otherwise traversal length varies pixel to pixel and lanes are refilled from dynamically fetched chunks
       if (d == 0 && fused && c->info.numNodes <= 64)
         rc = launchTrace<PRIMARY_GROUP>(c, numSlots, 0, sampBegin, tmin, tmax, nullptr, false, false, &g);
+      else if (d == 0 && fused && packets)
+        rc = launchTracePacket<PRIMARY>(c, numSlots, 0, sampBegin, tmin, tmax, nullptr, false, false, &g);
       else if (d == 0 && fused)
         rc = launchTrace<PRIMARY>(c, numSlots, 0, sampBegin, tmin, tmax, nullptr, false, false, &g);
       else
@@ -700,11 +743,12 @@ int calibrateRefill(rthip_ctx* c)
   const uint32_t keepBegin = c->lastBatchBegin, keepCount = c->lastBatchCount, keepSamp = c->lastSamp;
   const bool keepRendered = c->renderedAny, keepTiming = c->kernelTiming;
   c->kernelTiming = false;
-  float ms[2] = {0, 0};
+  float ms[3] = {0, 0, 0};
   int rc = 0;
-  for (int run = 0; run < 3 && !rc; ++run)
+  const int runs = packetsPossible(c) && c->fusedPrimary ? 4 : 3;
+  for (int run = 0; run < runs && !rc; ++run)
   {
-    c->refillMode = run == 2 ? 1 : 0;
+    c->refillMode = run == 0 ? 0 : run - 1;
     rc = (int)hipEventRecord(c->evA, c->stream);
     if (!rc)
       rc = renderBatch(c, 0, samples, first, tiles, false, nullptr, true);
@@ -722,8 +766,13 @@ int calibrateRefill(rthip_ctx* c)
     c->refillMode = 0;
     return rc;
   }
-  c->refillMs[0] = ms[0], c->refillMs[1] = ms[1];
-  c->refillMode = ms[1] < 0.98f * ms[0] ? 1 : 0; // the high thresholds must win by more than the noise of the measurement
+  c->refillMs[0] = ms[0], c->refillMs[1] = ms[1], c->refillMs[2] = ms[2];
+  // anything but the low thresholds must win by more than the noise of the measurement
+  c->refillMode = 0;
+  float bestMs = 0.98f * ms[0];
+  for (int m = 1; m < runs - 1; ++m)
+    if (ms[m] < bestMs)
+      bestMs = ms[m], c->refillMode = m;
   c->refillKey = key;
   return 0;
 }
@@ -853,7 +902,7 @@ static int createContext(rthip_ctx* c, int device)
   if (const char* t = getenv("RTHIP_CALIB_LOG2"))
     c->calibLog2 = (uint32_t)std::max(16, std::min(27, atoi(t)));
   if (const char* t = getenv("RTHIP_REFILL_MODE")) // 0 / 1: fixed low / high refill thresholds instead of the measured choice
-    c->refillWanted = atoi(t) ? 1 : 0;
+    c->refillWanted = std::max(0, std::min(2, atoi(t)));
   if (const char* t = getenv("RTHIP_GROUP_LG"))
     c->groupLg = atoi(t);
   c->traceBlocks = (uint32_t)c->numCUs * c->tuneBlocks; // 6 blocks x 4 waves = 24 waves per CU: what 24 KB of LDS per block admits
@@ -1387,21 +1436,21 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
 
 int rthip_set_refill_mode(rthip_ctx* c, int mode)
 {
-  if (!c || mode < -1 || mode > 1)
+  if (!c || mode < -1 || mode > 2)
     return RTHIP_E_ARG;
   c->refillWanted = mode;
   c->refillKey = 0; // (back to -1: measure again at the next rthip_begin)
   return 0;
 }
 
-int rthip_get_refill_mode(rthip_ctx* c, int* modeOut, float msOut[2])
+int rthip_get_refill_mode(rthip_ctx* c, int* modeOut, float msOut[3])
 {
   if (!c)
     return RTHIP_E_ARG;
   if (modeOut)
     *modeOut = c->refillMode;
   if (msOut)
-    msOut[0] = c->refillMs[0], msOut[1] = c->refillMs[1];
+    msOut[0] = c->refillMs[0], msOut[1] = c->refillMs[1], msOut[2] = c->refillMs[2];
   return 0;
 }
 

@@ -124,6 +124,15 @@ def test_config3_heightfield_10m_triangles_4k_64spp(hf10m):
     assert np.array_equal(full.view(np.uint32), r.accumulator().view(np.uint32))
     assert r.counters() == c
     assert full.min() >= 0 and np.isfinite(full).all()
+    # every traversal mode (per-lane with early / late refill, packets for camera and first shadow rays) at full size: same bits
+    for mode in (0, 1, 2):
+        r.set_option("refillMode", mode)
+        r.begin_frame(spec.product_camera(), W, H, S)
+        assert r.refill_mode()[0] == mode
+        r.render_passes(0, S)
+        assert np.array_equal(full.view(np.uint32), r.accumulator().view(np.uint32)), mode
+        assert r.counters() == c, mode
+    r.set_option("refillMode", -1)
 
 
 def test_config4_heightfield_8k_256spp_depth12(hf10m):
