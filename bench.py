@@ -55,7 +55,7 @@ def workloads():
     }
 
 
-KERNEL_NAMES = {"extend": "k_trace<PRIMARY|CLOSEST> (extend)", "shadow": "k_trace<SHADOW>", "generate": "k_generate", "shade": "k_shade",
+KERNEL_NAMES = {"extend": "k_trace<PRIMARY|CLOSEST> / k_trace_packet<PRIMARY> (extend)", "shadow": "k_trace<SHADOW> / k_trace_packet<SHADOW>", "generate": "k_generate", "shade": "k_shade",
                 "accumulate": "k_accumulate"}
 
 

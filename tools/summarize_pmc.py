@@ -14,22 +14,24 @@ import re
 import sys
 from collections import defaultdict
 
-MODES = {0: "CLOSEST", 1: "SHADOW", 2: "ANYPROBE", 3: "PRIMARY", 4: "PRIMARY_GROUP"}
+MODES = {0: "CLOSEST", 1: "SHADOW", 2: "ANYPROBE", 3: "PRIMARY", 4: "PRIMARY_GROUP", 5: "SHADOW_PT"}
 
 
 def short_name(full):
     s = full.replace("(anonymous namespace)::", "").replace("rtk::", "")
     s = re.sub(r"^void\s+", "", s)
-    m = re.match(r"k_trace<(\d+),\s*(true|false)>", s)
+    m = re.match(r"(k_trace|k_trace_packet)<(\d+),\s*(true|false)>", s)
     if m:
-        return "k_trace<%s%s>" % (MODES.get(int(m.group(1)), m.group(1)), ",COUNT" if m.group(2) == "true" else "")
+        return "%s<%s%s>" % (m.group(1), MODES.get(int(m.group(2)), m.group(2)), ",COUNT" if m.group(3) == "true" else "")
     m = re.match(r"(k_\w+)(<[^>]*>)?", s)
     return (m.group(1) + (m.group(2) or "")) if m else s.split("(")[0]
 
 
 def bench_key(name):
-    if name.startswith("k_trace<SHADOW"):
+    if name.startswith("k_trace<SHADOW") or name.startswith("k_trace_packet<SHADOW"):
         return "shadow"
+    if name.startswith("k_trace_packet<"):
+        return "extend"
     if name.startswith("k_trace<ANYPROBE"):
         return None
     if name.startswith("k_trace<"):
