@@ -204,6 +204,8 @@ struct rthip_ctx
   uint64_t refillKey = 0;        // what the current refillMode was measured for
   uint32_t sceneEpoch = 0;       // counts scene uploads
   float refillMs[3] = {0, 0, 0}; // the calibration timings (low, high, packets), for inspection
+  uint32_t packetBlocks = 8;     // resident blocks per CU of the packet kernel (RTHIP_PACKET_BLOCKS)
+  bool deepLow = true;           // bounce rays and the shadow rays of their hits are scattered whatever the camera rays were: low thresholds (RTHIP_DEEP_LOW=0: off; hf10m -2 %)
   uint32_t calibLog2 = 24;       // paths in the calibration sample (RTHIP_CALIB_LOG2): fewer, and launches are tail-bound, which hides the difference
   bool fusedPrimary = true;      // generate rays inside the depth-0 traversal kernel instead of storing them
   uint32_t lastBatchBegin = 0, lastBatchCount = 0, lastSamp = 0;
@@ -457,7 +459,7 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   a.tmin = tmin;
   a.tmax = tmax;
   a.anyOut = c->anyOut.p;
-  a.refillAt = c->refillMode >= 1 ? c->tuneRefillHi : (isShadow(MODE) ? c->tuneRefillShadow : (MODE == PRIMARY ? c->tuneRefillPrimary : c->tuneRefill));
+  a.refillAt = (c->refillMode >= 1 && !(c->deepLow && (depth >= 2 || MODE == CLOSEST))) ? c->tuneRefillHi : (isShadow(MODE) ? c->tuneRefillShadow : (MODE == PRIMARY ? c->tuneRefillPrimary : c->tuneRefill));
   a.leafTrigger = c->tuneLeaf;
   a.leafTriggerHi = c->tuneLeafHi;
   a.stealSpans = c->tuneSteal;
@@ -523,7 +525,7 @@ int launchTracePacket(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t 
   if (c->fetchCursor >= kMaxTraceLaunches)
     return RTHIP_E_LIMIT;
   a.fetch = fetchBase(c) + (size_t)(c->fetchCursor++) * kFetchShards * kFetchStride;
-  const uint32_t blocks = (uint32_t)c->numCUs * 8u; // 8 blocks x 4 waves: the kernel keeps within 64 VGPRs and uses no LDS
+  const uint32_t blocks = (uint32_t)c->numCUs * c->packetBlocks; // 8 blocks x 4 waves: the kernel keeps within 64 VGPRs and uses no LDS
   hipStream_t stream = sideStream ? c->stream2 : c->stream;
   KernelTimer kt(c, isClosest(MODE) ? 1 : 3, stream);
   if (c->countWork)
@@ -899,6 +901,10 @@ static int createContext(rthip_ctx* c, int device)
     if (v >= 16 && v <= 30)
       c->pathCap = 1ull << v;
   }
+  if (const char* t = getenv("RTHIP_PACKET_BLOCKS"))
+    c->packetBlocks = (uint32_t)std::max(1, std::min(16, atoi(t)));
+  if (const char* t = getenv("RTHIP_DEEP_LOW"))
+    c->deepLow = atoi(t) != 0;
   if (const char* t = getenv("RTHIP_CALIB_LOG2"))
     c->calibLog2 = (uint32_t)std::max(16, std::min(27, atoi(t)));
   if (const char* t = getenv("RTHIP_REFILL_MODE")) // 0 / 1: fixed low / high refill thresholds instead of the measured choice
