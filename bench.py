@@ -61,16 +61,18 @@ KERNEL_NAMES = {"extend": "k_trace<PRIMARY|CLOSEST> / k_trace_packet<PRIMARY> (e
 
 def roofline_block(workload, ktimes, wc, spp, ktimes_alone=None, scene_bytes=None):
     """roofline of the dominant kernel family.  `achieved` is ALGORITHMIC bytes per launch / average launch duration
-    (per ray 32 B ray record + 16 B hit record (any-hit: 4) + 64 B per node and per triangle record visited,
-    counted by the device).  Next to it: the HBM bytes the counters saw (profiles/traffic.json, from rocprofv3 --pmc passes
+    (per ray 32 B ray record + 16 B hit record (any-hit: 4) + 64 B per node and per triangle record the
+    launch fetches, counted by the device: a per-lane launch fetches every record a ray visits, a packet launch fetches a
+    record once for the 64 rays of a wave).  Next to it: the HBM bytes the counters saw (profiles/traffic.json, from rocprofv3 --pmc passes
     of this same command, FETCH_SIZE x2 + WRITE_SIZE) and the VALU issue rate, each against its own peak; `bound` names the
     ceiling the kernel is closest to, by that evidence (None when no counter data exists for the workload)."""
     n_ext = wc["extendPrimary"] + wc["extendSecondary"]
     n_paths = wc["extendPrimary"]
     alg_bytes = {
         # fused primary rays are never stored: they carry a hit record only
-        "extend": 16.0 * wc["extendPrimary"] + 48.0 * wc["extendSecondary"] + 64.0 * (wc["nodesVisitedExtend"] + wc["trisTestedExtend"]),
-        "shadow": 36.0 * wc["shadow"] + 64.0 * ((wc["nodesVisited"] - wc["nodesVisitedExtend"]) + (wc["trisTested"] - wc["trisTestedExtend"])),
+        # 64 B per scene record FETCHED: per ray by the per-lane launches, once per wave by the packet launches (rthip_counters)
+        "extend": 16.0 * wc["extendPrimary"] + 48.0 * wc["extendSecondary"] + 64.0 * wc["recordsFetchedExtend"],
+        "shadow": 36.0 * wc["shadow"] + 64.0 * wc["recordsFetchedShadow"],
         "generate": 32.0 * n_paths,
         "shade": (32.0 + 16.0 + 32.0) * n_ext,                # ray + hit read, next ray written, per shaded ray
         "accumulate": 24.0 * n_paths / spp + 17.0 * n_paths,  # accumulator read+write per pixel + radiance and liveness byte per sample
@@ -359,6 +361,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     cnt = r.counters()  # totals of the LAST frame (begin_frame resets them)
+    _mode, _cal = r.refill_mode()
     if dynamic:
         cnt = {"extendPrimary": step_rays[1], "extendSecondary": step_rays[2], "shadow": step_rays[3]}
     rays_local = cnt["extendPrimary"] + cnt["extendSecondary"] + cnt["shadow"]
@@ -459,7 +462,6 @@ def main():
     if not args.no_cpu_baseline:
         cpu = cpu_baseline(spec, wl, flat, args.cpu_seconds)
 
-    _mode, _cal = r.refill_mode()
     refill_info = {"mode": ("low refill thresholds (incoherent rays)", "high refill thresholds (coherent rays)", "packet traversal of camera and shadow rays")[_mode],
                    "calibration_ms_low_high_packet": [round(float(v), 3) for v in _cal],
                    "note": "how a wave treats its 64 rays, measured once per scene and frame shape before the warm-up step (rthip_set_refill_mode)"}

@@ -74,6 +74,11 @@ typedef struct rthip_counters
   uint64_t trisTestedExtend;
   uint64_t waveNodeSteps;   /* work counting: node steps / leaf steps executed by whole waves; x64 = lane slots offered, */
   uint64_t waveLeafSteps;   /* so nodesVisited / (64*waveNodeSteps) is the SIMD utilisation of the node step */
+  /* work counting: 64-byte scene records (nodes + triangles) the traversal launches FETCHED.  A per-lane launch fetches every
+   * record a ray visits, so these equal nodesVisited + trisTested of its rays; a packet launch fetches a record once for the
+   * 64 rays of a wave, however many of them visit it.  These are the bytes the algorithm has to move. */
+  uint64_t recordsFetchedExtend;
+  uint64_t recordsFetchedShadow;
 } rthip_counters;
 
 /* creates a context on `device` (a HIP device ordinal); replaces nothing in the reference (it has no device) */

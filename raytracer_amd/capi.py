@@ -39,7 +39,8 @@ class Counters(C.Structure):  # rthip_counters
     _fields_ = [("extendPrimary", C.c_uint64), ("extendSecondary", C.c_uint64), ("shadow", C.c_uint64),
                 ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64), ("nonFiniteAccepts", C.c_uint64),
                 ("hits", C.c_uint64 * 16), ("nodesVisitedExtend", C.c_uint64), ("trisTestedExtend", C.c_uint64),
-                ("waveNodeSteps", C.c_uint64), ("waveLeafSteps", C.c_uint64)]
+                ("waveNodeSteps", C.c_uint64), ("waveLeafSteps", C.c_uint64),
+                ("recordsFetchedExtend", C.c_uint64), ("recordsFetchedShadow", C.c_uint64)]
 
     def as_dict(self):
         d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "hits"}

@@ -73,6 +73,7 @@ struct DeviceCounters
 {
   unsigned long long extendPrimary, extendSecondary, shadow, nodesVisited, trisTested, nonFinite, nodesExtend, trisExtend;
   unsigned long long waveNodeSteps, waveLeafSteps; // work counting: node / leaf steps executed by waves (x64 = lane slots offered)
+  unsigned long long fetchExtend, fetchShadow;     // work counting: 64-byte scene records fetched (per lane, or per wave by packet launches)
   unsigned long long hits[16];
   unsigned long long alive[kMaxDepthSlots + 2]; // paths alive at each depth of the current batch
   uint32_t listCount[kMaxDepthSlots + 2];       // sparse mode: entries of the slot list of each depth

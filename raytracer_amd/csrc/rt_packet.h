@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
   const uint32_t chunkLen = max(64u, min((((total + waves * 8u - 1) / (waves * 8u)) + 63u) & ~63u, 2048u));
   const uint32_t chunksPerShard = ((total + kFetchShards - 1) / kFetchShards + chunkLen - 1) / chunkLen;
   uint32_t shardsDone = 0;
-  uint32_t nRays = 0, nNodes = 0, nTris = 0, nNodeSteps = 0, nLeafSteps = 0;
+  uint32_t nRays = 0, nNodes = 0, nTris = 0, nNodeSteps = 0, nLeafSteps = 0, nFetched = 0; // nFetched: records loaded by the wave
   uint32_t stackRef = 0, stackLo = 0, stackHi = 0; // the wave stack (see laneStackWrite)
 
   while (shardsDone < kFetchShards)
@@ -146,6 +146,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
         {
           // rtflat_model_node: lo[3] hi[3] left right blas triCount indicesOffset orderBase modelIndex subtreeSize pad[2]
           const record16 mn = loadRecord(modelNodes + mk);
+          if (COUNT)
+            nFetched++;
           const uint32_t subtree = (uint32_t)mn[13], triCount = (uint32_t)mn[9];
           bool passed = false;
           if (live && mk >= skipUntil)
@@ -183,6 +185,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
               for (uint32_t k = 0; k < count; ++k)
               {
                 const record16 tr = loadRecord(tris4 + (size_t)(first + k) * 4);
+                if (COUNT)
+                  nFetched++;
                 const float4 a0 = recordQuarter(tr, 0), a1 = recordQuarter(tr, 1), a2 = recordQuarter(tr, 2);
                 if (mine && live)
                 {
@@ -223,6 +227,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
               if (COUNT)
                 nNodeSteps++;
               const record16 nd = loadRecord(nodes4 + (size_t)cur * 4);
+              if (COUNT)
+                nFetched++;
               const float4 w0 = recordQuarter(nd, 0), w2 = recordQuarter(nd, 2), w3 = recordQuarter(nd, 3);
               bool h0 = false, h1 = false, h2 = false, h3 = false;
               float en0 = 0, en1 = 0, en2 = 0, en3 = 0;
@@ -352,6 +358,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
     {
       atomicAdd(&a.counters->waveNodeSteps, (unsigned long long)nNodeSteps);
       atomicAdd(&a.counters->waveLeafSteps, (unsigned long long)nLeafSteps);
+      atomicAdd(kClosest ? &a.counters->fetchExtend : &a.counters->fetchShadow, (unsigned long long)nFetched);
       if (nNodes)
       {
         atomicAdd(&a.counters->nodesVisited, (unsigned long long)nNodes);

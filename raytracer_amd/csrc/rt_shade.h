@@ -368,6 +368,8 @@ __global__ void k_fold_counters(const DeviceCounters* batch, rthip_counters* tot
   add(&totals->trisTestedExtend, batch->trisExtend);
   add(&totals->waveNodeSteps, batch->waveNodeSteps);
   add(&totals->waveLeafSteps, batch->waveLeafSteps);
+  add(&totals->recordsFetchedExtend, batch->fetchExtend);
+  add(&totals->recordsFetchedShadow, batch->fetchShadow);
   for (int i = 0; i < 16; ++i)
     add(&totals->hits[i], batch->hits[i]);
 }

@@ -633,6 +633,8 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 6)) void k_tra
       atomicAdd(&a.counters->waveNodeSteps, (unsigned long long)nNodeSteps);
       atomicAdd(&a.counters->waveLeafSteps, (unsigned long long)nLeafSteps);
     }
+    if (COUNT && (nNodes || nTris)) // every lane fetches the records its ray visits
+      atomicAdd(isClosest(MODE) ? &a.counters->fetchExtend : &a.counters->fetchShadow, (unsigned long long)nNodes + nTris);
     if (COUNT && nNodes)
     {
       atomicAdd(&a.counters->nodesVisited, (unsigned long long)nNodes);

@@ -717,7 +717,7 @@ BatchPlan planBatches(const rthip_ctx* c, uint32_t count, const FrameGeom& g, ui
 int calibrateRefill(rthip_ctx* c)
 {
   const uint64_t key = ((uint64_t)c->sceneEpoch << 48) ^ ((uint64_t)c->geom.width << 32) ^ ((uint64_t)c->geom.height << 16) ^ ((uint64_t)c->geom.numSamples << 8) ^
-                       ((uint64_t)c->maxDepth << 2) ^ ((uint64_t)c->geom.numLocalTiles * 0x9E3779B97F4A7C15ull);
+                       ((uint64_t)c->maxDepth << 2) ^ 1ull; // (not the tile set: a rank that is handed other tiles of the same frame keeps its choice)
   if (c->refillWanted >= 0)
   {
     c->refillMode = c->refillWanted;
