@@ -173,7 +173,7 @@ struct rthip_ctx
   rthip_camera camera{};
   FrameGeom geom{};
   uint32_t maxDepth = 12, aovDepths = 0;
-  uint64_t pathCap = 1ull << 27; // most paths (slots) a launch batch may hold: about 80 B of state each, per slot set
+  uint64_t pathCap = 1ull << 28; // most paths (slots) a launch batch may hold: about 80 B of state each, per slot set (2 x 22 GB at most)
   int groupLg = -1;              // log2 pixels per micro-block of the slot layout (-1: 64 / samples of the batch, see sampleOf)
   std::vector<uint32_t> hostTileIds, hostTileXY;
   DevBuf<uint32_t> tileIds;
