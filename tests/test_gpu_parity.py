@@ -449,3 +449,35 @@ def test_refill_modes_render_the_same_bits_and_calibration_stays_inside_the_buff
     assert frames[0].any()
     for mode in (1, 2, -1):
         assert np.array_equal(frames[0].view(np.uint32), frames[mode].view(np.uint32)), mode
+
+
+@pytest.mark.parametrize("name,W,H,N,depth", [("bunny", 160, 160, 2, 4), ("hf", 192, 128, 3, 5), ("multi", 192, 160, 2, 6), ("box_glb", 200, 150, 3, 8),
+                                             ("soup", 160, 160, 2, 5), ("cube", 250, 130, 2, 3)])
+def test_packet_traversal_matches_oracle_bitexact(name, W, H, N, depth):
+    """The packet kernel (camera rays and the shadow rays of their hits traced one node at a time per wave, rt_packet.h) forced
+    on, against the oracle: hit ids, shadow masks, ray counts, accumulator.  Waves here hold 64 DIFFERENT pixels (few samples),
+    the worst case for packets and the one where lanes disagree most about which children to enter."""
+    spec = {"cube": scenes.cube_scene, "bunny": scenes.bunny_scene, "soup": scenes.soup_scene, "hf": scenes.heightfield_scene,
+            "multi": scenes.multi_model_scene, "box_glb": scenes.box_glb_scene}[name]()
+    aov = min(depth, 3)
+    want = spec.build_oracle().render(spec.oracle_camera(), W, H, N, max_depth=depth, aov_depths=aov, workers=14)
+    assert want["counters"]["nonFiniteAccepts"] == 0
+    r = spec.build_product(options=dict(maxDepth=depth, aovDepths=aov, refillMode=2))
+    r.begin_frame(spec.product_camera(), W, H, N)
+    assert r.refill_mode()[0] == 2
+    for s in range(N):
+        r.render_passes(s, 1)
+        for d in range(aov):
+            tri, sh = r.aov(s, d)
+            assert np.array_equal(tri, want["tri_id"][s, d]), (s, d, int((tri != want["tri_id"][s, d]).sum()))
+            assert np.array_equal(sh, want["shadow"][s, d]), (s, d, int((sh != want["shadow"][s, d]).sum()))
+    cnt, oc = r.counters(), want["counters"]
+    assert cnt["nonFiniteAccepts"] == 0 and cnt["extendPrimary"] == oc["extendPrimary"] and cnt["shadow"] == oc["shadow"]
+    assert cnt["hits"][:depth] == oc["hits"][:depth]
+    assert np.array_equal(r.accumulator().view(np.uint32), want["accumulator"].view(np.uint32))
+    # the same frame without AOVs, all passes in one call (the layout packets are meant for: a pixel's samples side by side)
+    r.set_option("aovDepths", 0)
+    r.begin_frame(spec.product_camera(), W, H, N)
+    r.render_passes(0, N)
+    assert np.array_equal(r.accumulator().view(np.uint32), want["accumulator"].view(np.uint32))
+    r.close()
