@@ -205,6 +205,7 @@ struct rthip_ctx
   uint32_t sceneEpoch = 0;       // counts scene uploads
   float refillMs[3] = {0, 0, 0}; // the calibration timings (low, high, packets), for inspection
   uint32_t packetBlocks = 8;     // resident blocks per CU of the packet kernel (RTHIP_PACKET_BLOCKS)
+  bool closestLow = true;        // (RTHIP_CLOSEST_LOW=0: the first bounce rays use the high threshold)
   bool deepLow = true;           // bounce rays and the shadow rays of their hits are scattered whatever the camera rays were: low thresholds (RTHIP_DEEP_LOW=0: off; hf10m -2 %)
   uint32_t calibLog2 = 24;       // paths in the calibration sample (RTHIP_CALIB_LOG2): fewer, and launches are tail-bound, which hides the difference
   bool fusedPrimary = true;      // generate rays inside the depth-0 traversal kernel instead of storing them
@@ -459,7 +460,7 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   a.tmin = tmin;
   a.tmax = tmax;
   a.anyOut = c->anyOut.p;
-  a.refillAt = (c->refillMode >= 1 && !(c->deepLow && (depth >= 2 || MODE == CLOSEST))) ? c->tuneRefillHi : (isShadow(MODE) ? c->tuneRefillShadow : (MODE == PRIMARY ? c->tuneRefillPrimary : c->tuneRefill));
+  a.refillAt = (c->refillMode >= 1 && !(c->deepLow && (depth >= 2 || (MODE == CLOSEST && c->closestLow)))) ? c->tuneRefillHi : (isShadow(MODE) ? c->tuneRefillShadow : (MODE == PRIMARY ? c->tuneRefillPrimary : c->tuneRefill));
   a.leafTrigger = c->tuneLeaf;
   a.leafTriggerHi = c->tuneLeafHi;
   a.stealSpans = c->tuneSteal;
@@ -903,6 +904,8 @@ static int createContext(rthip_ctx* c, int device)
   }
   if (const char* t = getenv("RTHIP_PACKET_BLOCKS"))
     c->packetBlocks = (uint32_t)std::max(1, std::min(16, atoi(t)));
+  if (const char* t = getenv("RTHIP_CLOSEST_LOW"))
+    c->closestLow = atoi(t) != 0;
   if (const char* t = getenv("RTHIP_DEEP_LOW"))
     c->deepLow = atoi(t) != 0;
   if (const char* t = getenv("RTHIP_CALIB_LOG2"))

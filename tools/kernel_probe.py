@@ -17,6 +17,7 @@ def main():
     W, H, N, depth = wl["width"], wl["height"], wl["spp"], wl["max_depth"]
     import os
     N = int(os.environ.get("RT_PROBE_SPP", N))
+    depth = int(os.environ.get("RT_PROBE_DEPTH", depth))
     extra = {}
     if os.environ.get("RT_PROBE_MATERIALS"):
         import numpy as np
