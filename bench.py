@@ -462,8 +462,9 @@ def main():
     if not args.no_cpu_baseline:
         cpu = cpu_baseline(spec, wl, flat, args.cpu_seconds)
 
-    refill_info = {"mode": ("low refill thresholds (incoherent rays)", "high refill thresholds (coherent rays)", "packet traversal of camera and shadow rays")[_mode],
-                   "calibration_ms_low_high_packet": [round(float(v), 3) for v in _cal],
+    refill_info = {"mode": ("low refill thresholds (incoherent rays)", "high refill thresholds (coherent rays)", "packet traversal of camera and shadow rays",
+                            "packet traversal of camera rays")[_mode],
+                   "calibration_ms_low_high_packet_camerapacket": [round(float(v), 3) for v in _cal],
                    "note": "how a wave treats its 64 rays, measured once per scene and frame shape before the warm-up step (rthip_set_refill_mode)"}
     out = {"metric": "Mrays/s (primary+secondary)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,

@@ -127,12 +127,12 @@ int rthip_set_point_shadows(rthip_ctx* ctx, int on);
  * 0 = every lane walks its own ray and idle lanes are refilled early (suits incoherent rays), 1 = the same but a wave runs
  * nearly empty before it takes new rays (suits coherent rays), 2 = camera rays and directional shadow rays are traced as
  * packets -- the wave visits one node at a time for all its rays -- and bounce rays as in 1 (suits very coherent rays: many
- * samples per pixel); -1 (default) = measured: the first rthip_begin after a scene upload or a change of the frame's shape
+ * samples per pixel), 3 = packets for the camera rays only; -1 (default) = measured: the first rthip_begin after a scene upload or a change of the frame's shape
  * traces a sample of the frame with each setting (tens of milliseconds, one host synchronisation) and keeps the fastest.
  * Results do not depend on it.  rthip_get_refill_mode reports the setting in use and the timings in ms (0 when none was
  * taken). */
 int rthip_set_refill_mode(rthip_ctx* ctx, int mode);
-int rthip_get_refill_mode(rthip_ctx* ctx, int* modeOut, float msOut[3]);
+int rthip_get_refill_mode(rthip_ctx* ctx, int* modeOut, float msOut[4]);
 
 /* Starts a frame: allocates and clears accumulator/image for the tiles of `frame`
  * (CPURenderer::render's prologue, src/cpu/CPURenderer.cpp:140-143). */

@@ -452,10 +452,10 @@ class Renderer:
         return dict(_owner=self, shade=view(sh, n_tris, SHADE_DTYPE), materials=view(mt, nm.value, MATERIAL_DTYPE), texels=texels)
 
     def refill_mode(self):
-        """(traversal mode in use: 0 low / 1 high refill thresholds / 2 packet traversal of camera and shadow rays,
-        [ms with each] of the last calibration -- zeros when none was taken)"""
+        """(traversal mode in use: 0 low / 1 high refill thresholds / 2 packet traversal of camera and first shadow rays / 3 of camera
+        rays only, [ms with each] of the last calibration -- zeros when none was taken)"""
         m = C.c_int()
-        ms = np.zeros(3, np.float32)
+        ms = np.zeros(4, np.float32)
         _check(hip_lib().rthip_get_refill_mode(self.context, C.byref(m), _fp(ms)), "rthip_get_refill_mode")
         return int(m.value), ms
 

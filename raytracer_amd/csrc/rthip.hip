@@ -203,8 +203,9 @@ struct rthip_ctx
   int refillWanted = -1, refillMode = 0;
   uint64_t refillKey = 0;        // what the current refillMode was measured for
   uint32_t sceneEpoch = 0;       // counts scene uploads
-  float refillMs[3] = {0, 0, 0}; // the calibration timings (low, high, packets), for inspection
+  float refillMs[4] = {0, 0, 0, 0}; // the calibration timings (low, high, packets, packets for camera rays only), for inspection
   uint32_t packetBlocks = 8;     // resident blocks per CU of the packet kernel (RTHIP_PACKET_BLOCKS)
+  bool packetShadow = true;      // (RTHIP_PACKET_SHADOW=0: packets for camera rays only)
   bool closestLow = true;        // (RTHIP_CLOSEST_LOW=0: the first bounce rays use the high threshold)
   bool deepLow = true;           // bounce rays and the shadow rays of their hits are scattered whatever the camera rays were: low thresholds (RTHIP_DEEP_LOW=0: off; hf10m -2 %)
   uint32_t calibLog2 = 24;       // paths in the calibration sample (RTHIP_CALIB_LOG2): fewer, and launches are tail-bound, which hides the difference
@@ -614,10 +615,10 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, uint32_t tileB
       HIPCHK(hipEventRecord(c->evFork, c->stream));
       HIPCHK(hipStreamWaitEvent(c->stream2, c->evFork, 0));
     }
-    const bool packets = c->refillMode == 2 && packetsPossible(c);
+    const bool packets = c->refillMode >= 2 && packetsPossible(c); // 2: camera rays and their hits' shadow rays, 3: camera rays only
     if (d > 0 && haveDirLights &&
         (rc = shadowPoints ? launchTrace<SHADOW_PT>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g)
-             : (packets && d == 1) ? launchTracePacket<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g) // the camera rays' hits: still one pixel per wave
+             : (packets && d == 1 && c->refillMode == 2 && c->packetShadow) ? launchTracePacket<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g) // the camera rays' hits: still one pixel per wave
                            : launchTrace<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g)))
       return rc;
     if (side)
@@ -746,8 +747,10 @@ int calibrateRefill(rthip_ctx* c)
   const uint32_t keepBegin = c->lastBatchBegin, keepCount = c->lastBatchCount, keepSamp = c->lastSamp;
   const bool keepRendered = c->renderedAny, keepTiming = c->kernelTiming;
   c->kernelTiming = false;
-  float ms[3] = {0, 0, 0};
+  float ms[4] = {0, 0, 0, 0};
   int rc = 0;
+  // (mode 3, packets for camera rays only, is a manual setting: alone on the GPU -- as here -- it loses where it wins by 3 % in
+  // the pipelined frame (hf10m at 4 spp), so measuring it would only pick it where mode 2 is better anyway)
   const int runs = packetsPossible(c) && c->fusedPrimary ? 4 : 3;
   for (int run = 0; run < runs && !rc; ++run)
   {
@@ -769,7 +772,7 @@ int calibrateRefill(rthip_ctx* c)
     c->refillMode = 0;
     return rc;
   }
-  c->refillMs[0] = ms[0], c->refillMs[1] = ms[1], c->refillMs[2] = ms[2];
+  c->refillMs[0] = ms[0], c->refillMs[1] = ms[1], c->refillMs[2] = ms[2], c->refillMs[3] = ms[3];
   // anything but the low thresholds must win by more than the noise of the measurement
   c->refillMode = 0;
   float bestMs = 0.98f * ms[0];
@@ -904,6 +907,8 @@ static int createContext(rthip_ctx* c, int device)
   }
   if (const char* t = getenv("RTHIP_PACKET_BLOCKS"))
     c->packetBlocks = (uint32_t)std::max(1, std::min(16, atoi(t)));
+  if (const char* t = getenv("RTHIP_PACKET_SHADOW"))
+    c->packetShadow = atoi(t) != 0;
   if (const char* t = getenv("RTHIP_CLOSEST_LOW"))
     c->closestLow = atoi(t) != 0;
   if (const char* t = getenv("RTHIP_DEEP_LOW"))
@@ -911,7 +916,7 @@ static int createContext(rthip_ctx* c, int device)
   if (const char* t = getenv("RTHIP_CALIB_LOG2"))
     c->calibLog2 = (uint32_t)std::max(16, std::min(27, atoi(t)));
   if (const char* t = getenv("RTHIP_REFILL_MODE")) // 0 / 1: fixed low / high refill thresholds instead of the measured choice
-    c->refillWanted = std::max(0, std::min(2, atoi(t)));
+    c->refillWanted = std::max(0, std::min(3, atoi(t)));
   if (const char* t = getenv("RTHIP_GROUP_LG"))
     c->groupLg = atoi(t);
   c->traceBlocks = (uint32_t)c->numCUs * c->tuneBlocks; // 6 blocks x 4 waves = 24 waves per CU: what 24 KB of LDS per block admits
@@ -1445,21 +1450,21 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
 
 int rthip_set_refill_mode(rthip_ctx* c, int mode)
 {
-  if (!c || mode < -1 || mode > 2)
+  if (!c || mode < -1 || mode > 3)
     return RTHIP_E_ARG;
   c->refillWanted = mode;
   c->refillKey = 0; // (back to -1: measure again at the next rthip_begin)
   return 0;
 }
 
-int rthip_get_refill_mode(rthip_ctx* c, int* modeOut, float msOut[3])
+int rthip_get_refill_mode(rthip_ctx* c, int* modeOut, float msOut[4])
 {
   if (!c)
     return RTHIP_E_ARG;
   if (modeOut)
     *modeOut = c->refillMode;
   if (msOut)
-    msOut[0] = c->refillMs[0], msOut[1] = c->refillMs[1], msOut[2] = c->refillMs[2];
+    msOut[0] = c->refillMs[0], msOut[1] = c->refillMs[1], msOut[2] = c->refillMs[2], msOut[3] = c->refillMs[3];
   return 0;
 }
 

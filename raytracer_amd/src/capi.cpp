@@ -254,7 +254,7 @@ int rt_set_option(rt_renderer* r, const char* name, double value)
   else if (n == "pipelining")
     return r->hip->context() ? rthip_set_pipelining(r->hip->context(), value != 0) : RTHIP_E_NODEVICE;
   else if (n == "refillMode")
-    return r->hip->context() ? rthip_set_refill_mode(r->hip->context(), value < 0 ? -1 : (int)std::min(2.0, value)) : RTHIP_E_NODEVICE;
+    return r->hip->context() ? rthip_set_refill_mode(r->hip->context(), value < 0 ? -1 : (int)std::min(3.0, value)) : RTHIP_E_NODEVICE;
   else if (n == "overlapShadow")
     return r->hip->context() ? rthip_set_overlap_shadow(r->hip->context(), value != 0) : RTHIP_E_NODEVICE;
   else if (n == "kernelTiming")

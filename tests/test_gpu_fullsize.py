@@ -125,7 +125,7 @@ def test_config3_heightfield_10m_triangles_4k_64spp(hf10m):
     assert r.counters() == c
     assert full.min() >= 0 and np.isfinite(full).all()
     # every traversal mode (per-lane with early / late refill, packets for camera and first shadow rays) at full size: same bits
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         r.set_option("refillMode", mode)
         r.begin_frame(spec.product_camera(), W, H, S)
         assert r.refill_mode()[0] == mode
