@@ -67,7 +67,7 @@ struct ShadeArgs
 // MAT: the scene carries materials (rthip_upload_materials): a hit's albedo / emissive come from its model's material at the
 // hit's texture coordinates and the albedo travels with the path (pb.alb) to the light fold one depth later.
 template <bool SPARSE, bool MAT>
-__global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
+__global__ __launch_bounds__(kBlock, 8) void k_shade(ShadeArgs a)
 {
   __shared__ uint32_t sKeep[kWavesPerBlock][kShadeRun];
   __shared__ uint32_t sAlive[kWavesPerBlock], sHits[kWavesPerBlock];
