@@ -118,6 +118,7 @@ def hip_lib():
         L.rthip_begin.argtypes = [vp, C.POINTER(Camera), C.POINTER(FrameDesc)]
         L.rthip_set_refill_mode.argtypes = [vp, C.c_int]
         L.rthip_get_refill_mode.argtypes = [vp, C.POINTER(C.c_int), fp]
+        L.rthip_get_grid_blocks.argtypes = [vp, C.POINTER(C.c_uint32)]
         _hip = L
     return _hip
 
@@ -453,11 +454,17 @@ class Renderer:
 
     def refill_mode(self):
         """(traversal mode in use: 0 low / 1 high refill thresholds / 2 packet traversal of camera and first shadow rays / 3 of camera
-        rays only, [ms with each] of the last calibration -- zeros when none was taken)"""
+        rays only, [ms of the last calibration: settings 0, 1, 2, then the chosen one with the small persistent grid] -- zeros when none was taken)"""
         m = C.c_int()
         ms = np.zeros(4, np.float32)
         _check(hip_lib().rthip_get_refill_mode(self.context, C.byref(m), _fp(ms)), "rthip_get_refill_mode")
         return int(m.value), ms
+
+    def grid_blocks(self):
+        """resident blocks per CU of the traversal kernel's persistent grid (6, or 3 when the calibration found that faster)"""
+        b = C.c_uint32()
+        _check(hip_lib().rthip_get_grid_blocks(self.context, C.byref(b)), "rthip_get_grid_blocks")
+        return int(b.value)
 
     def build_times(self):
         """(host seconds of the flattener, device milliseconds of the BVH build -- 0 unless option deviceBvh was set)"""

@@ -151,7 +151,7 @@ struct rthip_ctx
   hipEvent_t evFork = nullptr, evJoin = nullptr;
   hipEvent_t evA = nullptr, evB = nullptr, evK0 = nullptr, evK1 = nullptr;
   int numCUs = 256;
-  uint32_t traceBlocks = 2048; // persistent grid of the dynamic mode
+  uint32_t traceBlocks = 2048; // persistent grid of the list launches (depth >= 1); dense launches use traceBlocksMax
   uint32_t fetchCursor = 0;    // next unused counter set of the current batch
   // scene
   bool haveScene = false;
@@ -192,7 +192,10 @@ struct rthip_ctx
   DevBuf<uint32_t> spill2;       // stack spill area of launches on stream2
   DevBuf<uint32_t> listA, listB; // slot lists of the paths alive at even / odd depths (one entry per slot of the batch at most)
   uint32_t spillCap = 1;         // per-lane spill entries the uploaded BVH can need
-  uint32_t tuneBlocks = 6;
+  uint32_t tuneBlocks = 6;       // resident blocks per CU of k_trace's persistent grid (what 24 KB of LDS per block admits) ...
+  uint32_t tuneBlocksLow = 3;    // ... and the small grid the calibration may pick instead (see calibrateRefill)
+  bool blocksFixed = false;      // RTHIP_TUNE named the grid: no measuring
+  uint32_t traceBlocksMax = 2048; // numCUs * tuneBlocks: what the spill areas are sized for
   uint32_t overlapShadow = 1;    // run a depth's shadow and closest-hit launches on two streams (their tails overlap)
   uint32_t tuneSteal = 1; // spans a wave may pull chunks from (1 = its own only; stealing measured +4% on the 1M soup, -4% on the bunny: off)
   uint32_t tuneRefill = kRefillThreshold, tuneLeaf = kLeafTrigger, tuneLeafHi = kLeafTriggerHi;
@@ -410,12 +413,12 @@ void staticGeometry(uint32_t total, uint32_t& blocks, uint32_t& runLen)
 // dynamic mode: persistent grid, chunks sized so that every resident wave fetches ~8 times when there is that much work
 void dynamicGeometry(const rthip_ctx* c, uint32_t total, uint32_t& blocks, uint32_t& chunkLen)
 {
-  const uint32_t waves = c->traceBlocks * kWavesPerBlock;
+  const uint32_t waves = c->traceBlocksMax * kWavesPerBlock;
   uint32_t cl = (total + waves * 8u - 1) / (waves * 8u);
   cl = ((cl + 63u) / 64u) * 64u;
   chunkLen = std::max(64u, std::min(cl, 4u * kChunk)); // a fetched span is scanned kChunk items at a time
   const uint32_t wavesNeeded = (total + chunkLen - 1) / chunkLen;
-  blocks = std::max(kFetchShards, std::min(c->traceBlocks, (wavesNeeded + kWavesPerBlock - 1) / kWavesPerBlock));
+  blocks = std::max(kFetchShards, std::min(c->traceBlocksMax, (wavesNeeded + kWavesPerBlock - 1) / kWavesPerBlock));
 }
 
 int ensurePathBuffers(rthip_ctx* c, size_t numSlots)
@@ -428,7 +431,7 @@ int ensurePathBuffers(rthip_ctx* c, size_t numSlots)
     return rc;
   uint32_t blocks, runLen;
   staticGeometry((uint32_t)numSlots, blocks, runLen);
-  blocks = std::max(blocks, c->traceBlocks);
+  blocks = std::max(blocks, c->traceBlocksMax);
   if ((rc = c->spill.ensure((size_t)c->spillCap * blocks * kBlock)) || (rc = c->spill2.ensure((size_t)c->spillCap * blocks * kBlock)))
     return rc;
   if ((rc = c->fetch.ensure(kCounterWords + (size_t)kMaxTraceLaunches * kFetchShards * kFetchStride)))
@@ -720,18 +723,22 @@ int calibrateRefill(rthip_ctx* c)
 {
   const uint64_t key = ((uint64_t)c->sceneEpoch << 48) ^ ((uint64_t)c->geom.width << 32) ^ ((uint64_t)c->geom.height << 16) ^ ((uint64_t)c->geom.numSamples << 8) ^
                        ((uint64_t)c->maxDepth << 2) ^ 1ull; // (not the tile set: a rank that is handed other tiles of the same frame keeps its choice)
+  const uint32_t fixedBlocks = std::min(c->traceBlocksMax, (uint32_t)c->numCUs * c->tuneBlocksLow); // (RTHIP_LIST_BLOCKS)
   if (c->refillWanted >= 0)
   {
     c->refillMode = c->refillWanted;
+    c->traceBlocks = c->blocksFixed ? fixedBlocks : c->traceBlocksMax;
     return 0;
   }
   if (c->aovDepths)
   {
     c->refillMode = 0; // AOV frames are parity runs: no timing runs between them
+    c->traceBlocks = c->blocksFixed ? fixedBlocks : c->traceBlocksMax;
     return 0;
   }
   if (key == c->refillKey)
     return 0;
+  c->traceBlocks = c->blocksFixed ? fixedBlocks : c->traceBlocksMax;
   const uint32_t perTile = c->geom.tileSize * c->geom.tileSize;
   const uint32_t samples = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(c->geom.numSamples, 64u), c->pathCap / perTile));
   const uint64_t wantTiles = std::max<uint64_t>(1, (1ull << c->calibLog2) / ((uint64_t)perTile * samples));
@@ -752,9 +759,7 @@ int calibrateRefill(rthip_ctx* c)
   // (mode 3, packets for camera rays only, is a manual setting: alone on the GPU -- as here -- it loses where it wins by 3 % in
   // the pipelined frame (hf10m at 4 spp), so measuring it would only pick it where mode 2 is better anyway)
   const int runs = packetsPossible(c) && c->fusedPrimary ? 4 : 3;
-  for (int run = 0; run < runs && !rc; ++run)
-  {
-    c->refillMode = run == 0 ? 0 : run - 1;
+  auto timedRun = [&](float* msOut) {
     rc = (int)hipEventRecord(c->evA, c->stream);
     if (!rc)
       rc = renderBatch(c, 0, samples, first, tiles, false, nullptr, true);
@@ -762,23 +767,43 @@ int calibrateRefill(rthip_ctx* c)
       rc = (int)hipEventRecord(c->evB, c->stream);
     if (!rc)
       rc = (int)hipEventSynchronize(c->evB);
-    if (!rc && run > 0)
-      rc = (int)hipEventElapsedTime(&ms[run - 1], c->evA, c->evB);
+    if (!rc && msOut)
+      rc = (int)hipEventElapsedTime(msOut, c->evA, c->evB);
+  };
+  for (int run = 0; run < runs && !rc; ++run)
+  {
+    c->refillMode = run == 0 ? 0 : run - 1;
+    timedRun(run > 0 ? &ms[run - 1] : nullptr);
+  }
+  if (!rc)
+  {
+    // anything but the low thresholds must win by more than the noise of the measurement
+    c->refillMode = 0;
+    float bestMs = 0.98f * ms[0];
+    for (int m = 1; m < runs - 1; ++m)
+      if (ms[m] < bestMs)
+        bestMs = ms[m], c->refillMode = m;
+    // The size of the persistent grid of k_trace's list launches (depth >= 1), the same way.  Scattered rays finish one by
+    // one, and with fewer resident waves each wave gets more of the launch's rays to refill its idle lanes with (1 M soup:
+    // node-step lane use 0.41 -> 0.53 with 3 blocks per CU instead of 6, frame -4 %; hf10m -2 %); camera-ray launches fill
+    // the GPU anyway and would only lose latency hiding (hf10m at 4 spp +18 %), so they keep the full grid.
+    if (!c->blocksFixed && c->tuneBlocksLow < c->tuneBlocks)
+    {
+      c->traceBlocks = (uint32_t)c->numCUs * c->tuneBlocksLow;
+      timedRun(&ms[3]);
+      if (rc || !(ms[3] < 0.98f * ms[c->refillMode]))
+        c->traceBlocks = c->traceBlocksMax;
+    }
   }
   c->kernelTiming = keepTiming;
   c->lastBatchBegin = keepBegin, c->lastBatchCount = keepCount, c->lastSamp = keepSamp, c->renderedAny = keepRendered;
   if (rc)
   {
     c->refillMode = 0;
+    c->traceBlocks = c->blocksFixed ? fixedBlocks : c->traceBlocksMax;
     return rc;
   }
   c->refillMs[0] = ms[0], c->refillMs[1] = ms[1], c->refillMs[2] = ms[2], c->refillMs[3] = ms[3];
-  // anything but the low thresholds must win by more than the noise of the measurement
-  c->refillMode = 0;
-  float bestMs = 0.98f * ms[0];
-  for (int m = 1; m < runs - 1; ++m)
-    if (ms[m] < bestMs)
-      bestMs = ms[m], c->refillMode = m;
   c->refillKey = key;
   return 0;
 }
@@ -899,6 +924,12 @@ static int createContext(rthip_ctx* c, int device)
     if (n >= 6)
       c->pipelineBatches = std::min(pl, 16u);
   }
+  if (const char* t = getenv("RTHIP_LIST_BLOCKS")) // blocks per CU of the list launches (depth >= 1), fixed instead of measured
+  {
+    const int v = atoi(t);
+    if (v >= 1 && v <= 8)
+      c->tuneBlocksLow = (uint32_t)v, c->blocksFixed = true;
+  }
   if (const char* t = getenv("RTHIP_PATHCAP_LOG2")) // tuning experiments only
   {
     const int v = atoi(t);
@@ -919,7 +950,8 @@ static int createContext(rthip_ctx* c, int device)
     c->refillWanted = std::max(0, std::min(3, atoi(t)));
   if (const char* t = getenv("RTHIP_GROUP_LG"))
     c->groupLg = atoi(t);
-  c->traceBlocks = (uint32_t)c->numCUs * c->tuneBlocks; // 6 blocks x 4 waves = 24 waves per CU: what 24 KB of LDS per block admits
+  c->traceBlocksMax = (uint32_t)c->numCUs * c->tuneBlocks; // 6 blocks x 4 waves = 24 waves per CU: what 24 KB of LDS per block admits
+  c->traceBlocks = c->blocksFixed ? std::min(c->traceBlocksMax, (uint32_t)c->numCUs * c->tuneBlocksLow) : c->traceBlocksMax;
   // the static scratch of rthip_trace_rays_static: resolved once per device, with that device current
   if (device < kMaxDevices && !g_scratchPtr[device])
   {
@@ -1454,6 +1486,14 @@ int rthip_set_refill_mode(rthip_ctx* c, int mode)
     return RTHIP_E_ARG;
   c->refillWanted = mode;
   c->refillKey = 0; // (back to -1: measure again at the next rthip_begin)
+  return 0;
+}
+
+int rthip_get_grid_blocks(rthip_ctx* c, uint32_t* blocksPerCuOut)
+{
+  if (!c || !blocksPerCuOut)
+    return RTHIP_E_ARG;
+  *blocksPerCuOut = c->traceBlocks / (uint32_t)std::max(1, c->numCUs);
   return 0;
 }
 

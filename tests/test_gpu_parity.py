@@ -424,8 +424,8 @@ def test_gather_over_rccl_single_rank_communicator():
 
 @pytest.mark.parametrize("W,H,N", [(96, 64, 1), (640, 360, 4), (300, 200, 70), (1920, 1080, 2)])
 def test_refill_modes_render_the_same_bits_and_calibration_stays_inside_the_buffers(W, H, N):
-    """The refill thresholds of the traversal launches (rthip_set_refill_mode) are a matter of speed only: low, high and the
-    measured choice give the same accumulator.  The measuring run traces a sample of the frame before the first pass; frame
+    """The refill thresholds of the traversal launches (rthip_set_refill_mode) and the size of their persistent grid are a
+    matter of speed only: low, high, packets and the measured choice give the same accumulator.  The measuring run traces a sample of the frame before the first pass; frame
     shapes whose whole frame is smaller than that sample, or whose batches are cut in two for the two slots, must keep it
     within what rthip_begin allocated (it once did not)."""
     spec = scenes.heightfield_scene(64)
@@ -435,9 +435,10 @@ def test_refill_modes_render_the_same_bits_and_calibration_stays_inside_the_buff
         r.begin_frame(spec.product_camera(), W, H, N)
         got, ms = r.refill_mode()
         if mode >= 0:
-            assert got == mode and not ms.any()
+            assert got == mode and not ms.any() and r.grid_blocks() == 6
         else:
-            assert got in (0, 1, 2) and (ms[:3] > 0).all(), "the first frame of a scene measures every setting"
+            assert got in (0, 1, 2) and (ms > 0).all(), "the first frame of a scene measures every setting, then the small grid"
+            assert r.grid_blocks() == (3 if ms[3] < 0.98 * ms[got] else 6)
         r.render_passes(0, N)
         frames[mode] = r.accumulator()
         if mode < 0:
