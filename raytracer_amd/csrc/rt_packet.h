@@ -31,6 +31,16 @@ __device__ __forceinline__ void laneStackWrite(uint32_t& reg, uint32_t value, ui
                : "s"(__builtin_amdgcn_readfirstlane(value)), "s"(__builtin_amdgcn_readfirstlane(index)));
 }
 __device__ __forceinline__ uint32_t laneStackRead(uint32_t reg, uint32_t index) { return (uint32_t)__builtin_amdgcn_readlane((int)reg, (int)index); }
+// Lane masks without vector instructions.  The compiler turns `__ballot(a <= b)` into compare + select + compare and a per-lane
+// `(mask >> lane) & 1` into two ANDs and a 64-bit compare -- 11 of a node visit's ~75 vector instructions, in a kernel whose
+// vector ALU port is taken 0.8-0.9 of the time.  A VOP3 compare writes the lane mask straight into an SGPR pair (inactive lanes
+// read as 0, NaN compares false, as `<=` does), and inverse_ballot hands a wave-uniform mask back as a per-lane condition.
+__device__ __forceinline__ uint64_t laneMaskLe(float a, float b)
+{
+  uint64_t m;
+  asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+  return m;
+}
 constexpr uint32_t kPacketStack = 64; // entries of the wave stack: the host only picks this kernel when 3 * (BVH depth) fits
 
 // k_trace for COHERENT rays (MODE = PRIMARY: camera rays, generated here; SHADOW: any-hit toward every directional light
@@ -139,6 +149,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
         best = FLT_MAX;
         bestRec = RTFLAT_INVALID;
         bool live = valid; // this lane's ray is still looking (an any-hit ray stops at its first accepted triangle)
+        uint64_t liveMask = __ballot(live); // the same, wave-wide
 
         // ---------------- model tree, pre-order, the whole wave at one node; a lane is inside node mk iff mk >= skipUntil
         uint32_t skipUntil = 0;
@@ -176,7 +187,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
           for (;;)
           {
             cur = __builtin_amdgcn_readfirstlane(cur);
-            const bool mine = live && ((curMask >> lane) & 1ull);
+            const uint64_t mineMask = curMask & liveMask; // the lanes whose ray is at this node and still looking
+            const bool mine = __builtin_amdgcn_inverse_ballot_w64(mineMask);
             if (rtflat_is_leaf(cur))
             {
               if (COUNT)
@@ -219,8 +231,12 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
                   }
                 }
               }
-              if (!kClosest && __ballot(live) == 0)
-                break; // every ray of the wave is occluded
+              if (!kClosest)
+              {
+                liveMask = __ballot(live);
+                if (liveMask == 0)
+                  break; // every ray of the wave is occluded
+              }
             }
             else
             {
@@ -230,22 +246,20 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
               if (COUNT)
                 nFetched++;
               const float4 w0 = recordQuarter(nd, 0), w2 = recordQuarter(nd, 2), w3 = recordQuarter(nd, 3);
-              bool h0 = false, h1 = false, h2 = false, h3 = false;
-              float en0 = 0, en1 = 0, en2 = 0, en3 = 0;
-              if (mine)
+              if (COUNT && mine)
+                nNodes++;
+              // every lane runs the box tests (a wave instruction costs the same for one lane as for 64; idle lanes carry a dummy
+              // ray); the masks keep the lanes that are at this node.  Unused slots have inverted boxes.
+              float en0, en1, en2, en3, ex0, ex1, ex2, ex3;
               {
-                if (COUNT)
-                  nNodes++;
                 const rtd::WideNode wn = rtd::wideNodeSetup(w0, w2, w3, invD, oi);
-                float ex0, ex1, ex2, ex3;
                 rtd::wideSlabPair<0>(wn, en0, ex0, en1, ex1);
                 rtd::wideSlabPair<2>(wn, en2, ex2, en3, ex3);
-                h0 = en0 <= ex0 && (!kClosest || en0 <= cull); // unused slots have inverted boxes
-                h1 = en1 <= ex1 && (!kClosest || en1 <= cull);
-                h2 = en2 <= ex2 && (!kClosest || en2 <= cull);
-                h3 = en3 <= ex3 && (!kClosest || en3 <= cull);
               }
-              uint64_t m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+              uint64_t m0 = laneMaskLe(en0, ex0) & mineMask, m1 = laneMaskLe(en1, ex1) & mineMask, m2 = laneMaskLe(en2, ex2) & mineMask,
+                       m3 = laneMaskLe(en3, ex3) & mineMask;
+              if (kClosest)
+                m0 &= laneMaskLe(en0, cull), m1 &= laneMaskLe(en1, cull), m2 &= laneMaskLe(en2, cull), m3 &= laneMaskLe(en3, cull);
               // children in the order of their entry distance along the first ray that hits each (any ray would do: the order
               // only decides how soon the culling distances shrink)
               uint32_t k0 = m0 ? (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(en0), (int)__builtin_ctzll(m0)) : 0xffffffffu;
