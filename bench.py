@@ -110,7 +110,8 @@ def roofline_block(workload, ktimes, wc, spp, ktimes_alone=None, scene_bytes=Non
         a_ms, a_launches = ktimes_alone[dominant]
         a_launch_s = a_ms * 1e-3 / max(1, a_launches)
         alone = {"avg_launch_ms": round(a_ms / max(1, a_launches), 5), "achieved": round(alg_bytes[dominant] / (a_ms * 1e-3) / 1e9, 2),
-                 "frac": round(alg_bytes[dominant] / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 # (no fraction of the HBM peak for an L2-resident scene: its record fetches never reach HBM, see cache_note)
+                 "frac": None if cache_note else round(alg_bytes[dominant] / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                  "frac_of_hbm_peak_counters": round(traffic / a_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                  "frac_of_valu_peak": round(valu_insts / a_launch_s / 1e9 / VALU_PEAK_GINST, 4) if valu_insts else None,
                  "kernel_ms_per_step": {k: round(v[0], 4) for k, v in ktimes_alone.items() if k in alg_bytes},
