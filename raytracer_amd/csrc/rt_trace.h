@@ -34,7 +34,9 @@ struct TraceArgs
 };
 
 template <int MODE, bool COUNT>
-__global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 6)) void k_trace(TraceArgs a)
+// (launch bounds: the per-lane modes need 66-79 VGPRs, so six blocks of four waves still fit a CU -- what 24 KB of LDS per block
+// admits; asking for six made the register allocator spill 12-28 bytes per lane to stay under 80, asking for four does not)
+__global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 4)) void k_trace(TraceArgs a)
 {
   __shared__ uint32_t sStack[kWavesPerBlock][kStackLds][64];
   __shared__ uint32_t sList[kWavesPerBlock][kChunk];
