@@ -16,7 +16,7 @@ constexpr uint32_t kChunk = 512;       // work items a wave scans and compacts a
 constexpr uint32_t kStackLds = 16;     // stack entries per lane kept in LDS
 constexpr uint32_t kMaxStack = 96;     // deepest triangle BVH accepted (LDS part + spill)
 constexpr uint32_t kLeafTrigger = 4;    // lanes that must be waiting on a leaf before a wave takes a leaf step (once no more arrive)
-constexpr uint32_t kLeafTriggerHi = 24; // ... or takes it regardless (see the leaf-step rule in k_trace)
+constexpr uint32_t kLeafTriggerHi = 16; // ... or takes it regardless (see the leaf-step rule in k_trace; 24 until the sweep of tools/ab_env.sh: 16 is 1.5-5 % faster on hf10m, soup1m and hf10m at 4 spp alike)
 constexpr uint32_t kDone = 0xffffffffu; // `cur`: the ray has no node, leaf or model left (== RTFLAT_INVALID)
 constexpr uint32_t kNone = 0xfffffffeu; // `cur` / `postponed`: empty
 constexpr uint32_t kRefillThreshold = 16; // refill once this many lanes are idle (or no lane is active): incoherent rays

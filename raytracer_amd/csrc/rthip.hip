@@ -197,7 +197,8 @@ struct rthip_ctx
   bool blocksFixed = false;      // RTHIP_TUNE named the grid: no measuring
   uint32_t traceBlocksMax = 2048; // numCUs * tuneBlocks: what the spill areas are sized for
   uint32_t overlapShadow = 1;    // run a depth's shadow and closest-hit launches on two streams (their tails overlap)
-  uint32_t tuneSteal = 1; // spans a wave may pull chunks from (1 = its own only; stealing measured +4% on the 1M soup, -4% on the bunny: off)
+  uint32_t tuneSteal = kFetchShards; // spans a wave may pull chunks from: its own first, then the others' (1 = its own only).  Off in round 1 (+4 % on the soup
+                                     // then); with lists and the measured grid it is -5 % on hf10m at 4 spp and neutral on hf10m / soup1m (tools/ab_env.sh)
   uint32_t tuneRefill = kRefillThreshold, tuneLeaf = kLeafTrigger, tuneLeafHi = kLeafTriggerHi;
   uint32_t tuneRefillShadow = kRefillThreshold, tuneRefillPrimary = 32; // the low thresholds of shadow / dynamic primary launches (RTHIP_TUNE fields 8, 9)
   uint32_t tuneRefillHi = kRefillCoherent;                              // the high threshold (field 10)
