@@ -467,9 +467,8 @@ def main():
     refill_info = {"mode": ("low refill thresholds (incoherent rays)", "high refill thresholds (coherent rays)", "packet traversal of camera and shadow rays",
                             "packet traversal of camera rays")[_mode],
                    "list_launch_blocks_per_cu": _grid,
-                   "calibration_ms_low_high_packet_chosen_on_small_grid": [round(float(v), 3) for v in _cal],
-                   "note": "how a wave treats its 64 rays and how many blocks per CU the launches of depth >= 1 get, measured once per scene and frame shape "
-                           "before the warm-up step (rthip_set_refill_mode, rthip_get_grid_blocks)"}
+                   "calibration_ms_low_high_packet": [round(float(v), 3) for v in _cal[:3]],
+                   "note": "how a wave treats its 64 rays, measured once per scene and frame shape before the warm-up step (rthip_set_refill_mode)"}
     out = {"metric": "Mrays/s (primary+secondary)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",

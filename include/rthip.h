@@ -130,9 +130,8 @@ int rthip_set_point_shadows(rthip_ctx* ctx, int on);
  * samples per pixel), 3 = packets for the camera rays only; -1 (default) = measured: the first rthip_begin after a scene upload or a change of the frame's shape
  * traces a sample of the frame with each setting (tens of milliseconds, one host synchronisation) and keeps the fastest.
  * Results do not depend on it.  rthip_get_refill_mode reports the setting in use and the timings in ms (0 when none was
- * taken): msOut[0..2] = settings 0, 1, 2; msOut[3] = the chosen setting once more with a persistent grid of 3 instead of 6
- * blocks per CU, which the same measurement keeps when it is faster (scattered rays: fewer waves, each with more rays to
- * refill its lanes from); rthip_get_grid_blocks reports the grid in use.  No counterpart in the reference (tuning only). */
+ * taken): msOut[0..2] = settings 0, 1, 2; msOut[3] is unused (0).  rthip_get_grid_blocks reports the resident blocks per CU
+ * of the launches of depth >= 1 (3; camera-ray launches use 6).  No counterpart in the reference (tuning only). */
 int rthip_set_refill_mode(rthip_ctx* ctx, int mode);
 int rthip_get_refill_mode(rthip_ctx* ctx, int* modeOut, float msOut[4]);
 int rthip_get_grid_blocks(rthip_ctx* ctx, uint32_t* blocksPerCuOut);

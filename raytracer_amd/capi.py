@@ -454,14 +454,14 @@ class Renderer:
 
     def refill_mode(self):
         """(traversal mode in use: 0 low / 1 high refill thresholds / 2 packet traversal of camera and first shadow rays / 3 of camera
-        rays only, [ms of the last calibration: settings 0, 1, 2, then the chosen one with the small persistent grid] -- zeros when none was taken)"""
+        rays only, [ms of the last calibration: settings 0, 1, 2; the fourth is unused] -- zeros when none was taken)"""
         m = C.c_int()
         ms = np.zeros(4, np.float32)
         _check(hip_lib().rthip_get_refill_mode(self.context, C.byref(m), _fp(ms)), "rthip_get_refill_mode")
         return int(m.value), ms
 
     def grid_blocks(self):
-        """resident blocks per CU of the traversal kernel's persistent grid (6, or 3 when the calibration found that faster)"""
+        """resident blocks per CU of the traversal kernel's launches over slot lists (depth >= 1): 3 unless RTHIP_LIST_BLOCKS says otherwise"""
         b = C.c_uint32()
         _check(hip_lib().rthip_get_grid_blocks(self.context, C.byref(b)), "rthip_get_grid_blocks")
         return int(b.value)

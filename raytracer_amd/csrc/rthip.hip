@@ -193,8 +193,7 @@ struct rthip_ctx
   DevBuf<uint32_t> listA, listB; // slot lists of the paths alive at even / odd depths (one entry per slot of the batch at most)
   uint32_t spillCap = 1;         // per-lane spill entries the uploaded BVH can need
   uint32_t tuneBlocks = 6;       // resident blocks per CU of k_trace's persistent grid (what 24 KB of LDS per block admits) ...
-  uint32_t tuneBlocksLow = 3;    // ... and the small grid the calibration may pick instead (see calibrateRefill)
-  bool blocksFixed = false;      // RTHIP_TUNE named the grid: no measuring
+  uint32_t tuneBlocksLow = 3;    // ... and of its launches over slot lists (depth >= 1), see launchTrace (RTHIP_LIST_BLOCKS)
   uint32_t traceBlocksMax = 2048; // numCUs * tuneBlocks: what the spill areas are sized for
   uint32_t overlapShadow = 1;    // run a depth's shadow and closest-hit launches on two streams (their tails overlap)
   uint32_t tuneSteal = kFetchShards; // spans a wave may pull chunks from: its own first, then the others' (1 = its own only).  Off in round 1 (+4 % on the soup
@@ -724,22 +723,18 @@ int calibrateRefill(rthip_ctx* c)
 {
   const uint64_t key = ((uint64_t)c->sceneEpoch << 48) ^ ((uint64_t)c->geom.width << 32) ^ ((uint64_t)c->geom.height << 16) ^ ((uint64_t)c->geom.numSamples << 8) ^
                        ((uint64_t)c->maxDepth << 2) ^ 1ull; // (not the tile set: a rank that is handed other tiles of the same frame keeps its choice)
-  const uint32_t fixedBlocks = std::min(c->traceBlocksMax, (uint32_t)c->numCUs * c->tuneBlocksLow); // (RTHIP_LIST_BLOCKS)
   if (c->refillWanted >= 0)
   {
     c->refillMode = c->refillWanted;
-    c->traceBlocks = c->blocksFixed ? fixedBlocks : c->traceBlocksMax;
     return 0;
   }
   if (c->aovDepths)
   {
     c->refillMode = 0; // AOV frames are parity runs: no timing runs between them
-    c->traceBlocks = c->blocksFixed ? fixedBlocks : c->traceBlocksMax;
     return 0;
   }
   if (key == c->refillKey)
     return 0;
-  c->traceBlocks = c->blocksFixed ? fixedBlocks : c->traceBlocksMax;
   const uint32_t perTile = c->geom.tileSize * c->geom.tileSize;
   const uint32_t samples = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(c->geom.numSamples, 64u), c->pathCap / perTile));
   const uint64_t wantTiles = std::max<uint64_t>(1, (1ull << c->calibLog2) / ((uint64_t)perTile * samples));
@@ -784,24 +779,12 @@ int calibrateRefill(rthip_ctx* c)
     for (int m = 1; m < runs - 1; ++m)
       if (ms[m] < bestMs)
         bestMs = ms[m], c->refillMode = m;
-    // The size of the persistent grid of k_trace's list launches (depth >= 1), the same way.  Scattered rays finish one by
-    // one, and with fewer resident waves each wave gets more of the launch's rays to refill its idle lanes with (1 M soup:
-    // node-step lane use 0.41 -> 0.53 with 3 blocks per CU instead of 6, frame -4 %; hf10m -2 %); camera-ray launches fill
-    // the GPU anyway and would only lose latency hiding (hf10m at 4 spp +18 %), so they keep the full grid.
-    if (!c->blocksFixed && c->tuneBlocksLow < c->tuneBlocks)
-    {
-      c->traceBlocks = (uint32_t)c->numCUs * c->tuneBlocksLow;
-      timedRun(&ms[3]);
-      if (rc || !(ms[3] < 0.98f * ms[c->refillMode]))
-        c->traceBlocks = c->traceBlocksMax;
-    }
   }
   c->kernelTiming = keepTiming;
   c->lastBatchBegin = keepBegin, c->lastBatchCount = keepCount, c->lastSamp = keepSamp, c->renderedAny = keepRendered;
   if (rc)
   {
     c->refillMode = 0;
-    c->traceBlocks = c->blocksFixed ? fixedBlocks : c->traceBlocksMax;
     return rc;
   }
   c->refillMs[0] = ms[0], c->refillMs[1] = ms[1], c->refillMs[2] = ms[2], c->refillMs[3] = ms[3];
@@ -929,7 +912,7 @@ static int createContext(rthip_ctx* c, int device)
   {
     const int v = atoi(t);
     if (v >= 1 && v <= 8)
-      c->tuneBlocksLow = (uint32_t)v, c->blocksFixed = true;
+      c->tuneBlocksLow = (uint32_t)v;
   }
   if (const char* t = getenv("RTHIP_PATHCAP_LOG2")) // tuning experiments only
   {
@@ -952,7 +935,12 @@ static int createContext(rthip_ctx* c, int device)
   if (const char* t = getenv("RTHIP_GROUP_LG"))
     c->groupLg = atoi(t);
   c->traceBlocksMax = (uint32_t)c->numCUs * c->tuneBlocks; // 6 blocks x 4 waves = 24 waves per CU: what 24 KB of LDS per block admits
-  c->traceBlocks = c->blocksFixed ? std::min(c->traceBlocksMax, (uint32_t)c->numCUs * c->tuneBlocksLow) : c->traceBlocksMax;
+  // Launches over slot lists (depth >= 1) get a smaller grid: scattered rays finish one by one, and with fewer resident waves
+  // each wave has more of the launch's rays to refill its idle lanes with (1 M soup: node-step lane use 0.41 -> 0.53), while
+  // the other batch in flight fills the rest of the GPU.  Camera-ray launches keep the full grid.  Frames queued back to back,
+  // list launches at 3 / 4 / 6 blocks per CU on one box: soup1m 3.28 / 3.38 / 3.47 ms, hf10m 165 / 167 / 169 ms, hf10m at 4 spp
+  // 18.8 / 18.9 / 19.6 ms, cube 1.05 / 1.06 / 1.18 ms.  (A single small frame alone on the GPU prefers 6 by up to 8 %.)
+  c->traceBlocks = std::min(c->traceBlocksMax, (uint32_t)c->numCUs * c->tuneBlocksLow);
   // the static scratch of rthip_trace_rays_static: resolved once per device, with that device current
   if (device < kMaxDevices && !g_scratchPtr[device])
   {

@@ -12,7 +12,7 @@ for r in $(seq 1 $ROUNDS); do
     for w in "${WL[@]}"; do
       set -- $w
       E=$(echo "$c" | tr '+' ' '); [ "$c" = "-" ] && E="RT_NONE=1"
-      env $E RTHIP_LIST_BLOCKS=${LIST_BLOCKS:-3} RTHIP_REFILL_MODE=$3 timeout -k 10 300 python tools/kernel_probe.py $1 $2 > gpurun_out/ab/o.txt 2>&1 || { tail -3 gpurun_out/ab/o.txt; exit 1; }
+      env RTHIP_LIST_BLOCKS=${LIST_BLOCKS:-3} RTHIP_REFILL_MODE=$3 $E timeout -k 10 300 python tools/kernel_probe.py $1 $2 > gpurun_out/ab/o.txt 2>&1 || { tail -3 gpurun_out/ab/o.txt; exit 1; }
       echo "$c $(grep -E 'pipelining=1' gpurun_out/ab/o.txt | cut -c1-62)"
     done
   done

@@ -11,9 +11,7 @@ for WL in hf10m soup1m; do
   STEPS=3; [ $WL = hf10m ] && STEPS=1
   # under rocprofv3 --pmc kernels run one at a time and slower, which could tip the traversal-mode calibration the other way:
   # the profiled runs are pinned to the mode the un-profiled bench measures for the workload (bench line: config.refill)
-  # (and to the small grid for the launches of depth >= 1, which the measurement picks for the soup and, at the margin, for hf10m)
   export RTHIP_REFILL_MODE=0; [ $WL = hf10m ] && export RTHIP_REFILL_MODE=2
-  export RTHIP_LIST_BLOCKS=3
   bash tools/profile_pmc.sh $TAG $WL $STEPS > gpurun_out/${TAG}_${WL}_pmc.log 2>&1 || { echo "pmc $WL failed"; tail -5 gpurun_out/${TAG}_${WL}_pmc.log; exit 1; }
   D=gpurun_out/kt_${TAG}_${WL}
   KS=10; [ $WL = hf10m ] && KS=4
@@ -22,7 +20,7 @@ for WL in hf10m soup1m; do
   grep "^{\"metric\"" gpurun_out/${TAG}_${WL}_kt.log | tail -n 1 > profiles/${TAG}_${WL}_bench_under_rocprof.json
   rm -rf $D gpurun_out/pmc_${TAG}_${WL}
 done
-unset RTHIP_REFILL_MODE RTHIP_LIST_BLOCKS
+unset RTHIP_REFILL_MODE
 timeout -k 10 300 python3 bench.py > profiles/${TAG}_hf10m_bench.json 2> gpurun_out/${TAG}_hf10m_bench.err || { echo "bench hf10m failed"; tail -5 gpurun_out/${TAG}_hf10m_bench.err; exit 1; }
 timeout -k 10 300 python3 bench.py --workload soup1m > profiles/${TAG}_soup1m_bench.json 2> gpurun_out/${TAG}_soup1m_bench.err || { echo "bench soup failed"; exit 1; }
 timeout -k 10 300 python3 bench.py --workload cube > profiles/${TAG}_cube_bench.json 2> gpurun_out/${TAG}_cube_bench.err || { echo "bench cube failed"; exit 1; }
