@@ -78,7 +78,10 @@ def roofline_block(workload, ktimes, wc, spp, ktimes_alone=None, scene_bytes=Non
         "accumulate": 24.0 * n_paths / spp + 17.0 * n_paths,  # accumulator read+write per pixel + radiance and liveness byte per sample
     }
     ktimes = {k: v for k, v in ktimes.items() if k in alg_bytes}
-    dominant = max(ktimes, key=lambda k: ktimes[k][0])
+    # the dominant family is the one that takes longest when every kernel has the GPU to itself: durations measured while
+    # batches overlap are stretched by whatever ran beside them, which makes two families of similar weight trade places
+    rank = {k: v for k, v in (ktimes_alone or {}).items() if k in ktimes and v[0] > 0} or ktimes
+    dominant = max(rank, key=lambda k: rank[k][0])
     k_ms, k_launches = ktimes[dominant]
     k_s = max(k_ms * 1e-3, 1e-12)
     achieved = alg_bytes[dominant] / k_s / 1e9
