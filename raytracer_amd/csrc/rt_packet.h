@@ -59,8 +59,9 @@ constexpr uint32_t kPacketStack = 64; // entries of the wave stack: the host onl
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
 {
-  static_assert(MODE == PRIMARY || MODE == SHADOW, "packet traversal serves camera rays and directional shadow rays");
+  static_assert(MODE == PRIMARY || MODE == SHADOW || MODE == SHADOW_PT, "packet traversal serves camera rays and shadow rays");
   constexpr bool kClosest = MODE == PRIMARY;
+  constexpr bool kShadow = MODE == SHADOW || MODE == SHADOW_PT;
   const uint32_t lane = laneId();
   const rtflat_model_node* __restrict__ modelNodes = a.scene.modelNodes;
   const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(a.scene.nodes);
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
       if (sparse && valid)
         slot = a.list[item];
       vec3 o{0, 0, 0}, d{0, 0, 1};
+      vec3 hitPos{0, 0, 0}, hitN{0, 0, 0}; // SHADOW_PT: the hit the shadow rays leave from (a point light's ray starts off the surface)
       float prevNx = 0.0f;
       if (MODE == PRIMARY)
       {
@@ -125,17 +127,35 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
         const float4 ro = a.pb.rayO[slot];
         o = vec3{ro.x, ro.y, ro.z};
         prevNx = ro.w;
+        if (MODE == SHADOW_PT)
+        {
+          hitPos = o;
+          hitN = vec3{ro.w, a.pb.s0[slot].w, a.pb.nz[slot]};
+        }
       }
       uint32_t occluded = 0;
       float best = FLT_MAX;
       uint32_t bestRec = RTFLAT_INVALID;
-      const uint32_t numPasses = MODE == PRIMARY ? 1u : a.lights->numDir;
+      const uint32_t numPasses = MODE == PRIMARY ? 1u : a.lights->numDir + (MODE == SHADOW_PT ? a.lights->numPoint : 0u);
       for (uint32_t pass = 0; pass < numPasses; ++pass)
       {
-        if (MODE == SHADOW)
+        float tmn = a.tmin, tmx = a.tmax;
+        const bool pointPass = MODE == SHADOW_PT && pass >= a.lights->numDir; // wave-uniform
+        if (pointPass)
+        {
+          // Compute.metal:238-254, as k_trace<SHADOW_PT> casts it: toward the light, not normalised (the light is at t = 1), from
+          // just off the surface, t in [0, 1]
+          const rthip_point_light& L = a.lights->point[pass - a.lights->numDir];
+          d = vec3{L.position[0], L.position[1], L.position[2]} - hitPos;
+          o = hitPos + hitN * 1e-3f;
+          tmn = 0.0f, tmx = 1.0f;
+        }
+        else if (kShadow)
         {
           const rthip_dir_light& L = a.lights->dir[pass];
           d = vec3{-L.direction[0], -L.direction[1], -L.direction[2]}; // Ray(position, -d.direction), CPUScene.cpp:34
+          if (MODE == SHADOW_PT)
+            o = hitPos;
         }
         if (valid)
           nRays++;
@@ -145,7 +165,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
         vec3 invRef = invD;
         if (fabsf(invD.x) == 1e18f || fabsf(invD.y) == 1e18f || fabsf(invD.z) == 1e18f)
           invRef = rt::rcp3(d);
-        float cull = FLT_MAX;
+        float cull = pointPass ? rt::fma(tmx, 1.0f + a.scene.cullRel, a.scene.cullAbs) : FLT_MAX; // boxes beyond a point light hold no accepted triangle
         best = FLT_MAX;
         bestRec = RTFLAT_INVALID;
         bool live = valid; // this lane's ray is still looking (an any-hit ray stops at its first accepted triangle)
@@ -167,7 +187,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
               nNodes++;
             const float lo[3] = {__int_as_float(mn[0]), __int_as_float(mn[1]), __int_as_float(mn[2])};
             const float hi[3] = {__int_as_float(mn[3]), __int_as_float(mn[4]), __int_as_float(mn[5])};
-            passed = rtd::refSlab(lo, hi, o, invRef, a.tmin, a.tmax); // CPUScene.cpp:109 / :125, the caller's tmin / tmax
+            passed = rtd::refSlab(lo, hi, o, invRef, tmn, tmx); // CPUScene.cpp:109 / :125, the caller's tmin / tmax
             if (!passed)
               skipUntil = mk + subtree;
           }
@@ -205,7 +225,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
                   if (COUNT)
                     nTris++;
                   float t;
-                  const int acc = rtd::triangleTest(vec3{a0.x, a0.y, a0.z}, vec3{a0.w, a1.x, a1.y}, vec3{a1.z, a1.w, a2.x}, o, d, a.tmin, a.tmax, t);
+                  const int acc = rtd::triangleTest(vec3{a0.x, a0.y, a0.z}, vec3{a0.w, a1.x, a1.y}, vec3{a1.z, a1.w, a2.x}, o, d, tmn, tmx, t);
                   if (acc == 2)
                     atomicAdd(&a.counters->nonFinite, 1ull);
                   if (acc == 1)
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
               }
               uint64_t m0 = laneMaskLe(en0, ex0) & mineMask, m1 = laneMaskLe(en1, ex1) & mineMask, m2 = laneMaskLe(en2, ex2) & mineMask,
                        m3 = laneMaskLe(en3, ex3) & mineMask;
-              if (kClosest)
+              if (kClosest || pointPass)
                 m0 &= laneMaskLe(en0, cull), m1 &= laneMaskLe(en1, cull), m2 &= laneMaskLe(en2, cull), m3 &= laneMaskLe(en3, cull);
               // children in the order of their entry distance along the first ray that hits each (any ray would do: the order
               // only decides how soon the culling distances shrink)
@@ -313,7 +333,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
           if (!kClosest && __ballot(live) == 0)
             break;
         }
-        if (MODE == SHADOW && valid && !live)
+        if (kShadow && valid && !live)
           occluded |= 1u << pass;
       }
 
@@ -338,7 +358,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
             const float4 al = a.pb.alb[slot];
             albedo = vec3{al.x, al.y, al.z};
           }
-          const vec3 radiance = foldLights(a.lights, occluded, o, vec3{prevNx, s0.w, a.pb.nz[slot]}, vec3{s0.x, s0.y, s0.z}, albedo, a.scene.pointShadows);
+          const vec3 radiance = foldLights(a.lights, occluded, MODE == SHADOW_PT ? hitPos : o, vec3{prevNx, s0.w, a.pb.nz[slot]}, vec3{s0.x, s0.y, s0.z}, albedo,
+                                           a.scene.pointShadows);
           if (a.depth - 1 < a.aovDepths)
           {
             uint32_t sidx, i;
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
   if (lane == 0)
   {
     if (nRays)
-      atomicAdd(MODE == SHADOW ? &a.counters->shadow : &a.counters->extendPrimary, (unsigned long long)nRays);
+      atomicAdd(kShadow ? &a.counters->shadow : &a.counters->extendPrimary, (unsigned long long)nRays);
     if (COUNT)
     {
       atomicAdd(&a.counters->waveNodeSteps, (unsigned long long)nNodeSteps);

@@ -620,9 +620,11 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, uint32_t tileB
     }
     const bool packets = c->refillMode >= 2 && packetsPossible(c); // 2: camera rays and their hits' shadow rays, 3: camera rays only
     if (d > 0 && haveDirLights &&
-        (rc = shadowPoints ? launchTrace<SHADOW_PT>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g)
-             : (packets && d == 1 && c->refillMode == 2 && c->packetShadow) ? launchTracePacket<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g) // the camera rays' hits: still one pixel per wave
-                           : launchTrace<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g)))
+        (rc = (packets && d == 1 && c->refillMode == 2 && c->packetShadow) // the camera rays' hits: still one pixel per wave
+                  ? (shadowPoints ? launchTracePacket<SHADOW_PT>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g)
+                                  : launchTracePacket<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g))
+                  : (shadowPoints ? launchTrace<SHADOW_PT>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g)
+                                  : launchTrace<SHADOW>(c, numSlots, d, sampBegin, tmin, tmax, list, last, side, &g))))
       return rc;
     if (side)
     {

@@ -63,6 +63,19 @@ def test_materials_and_point_shadows_match_oracle_bitexact(name, depth, material
         assert (want["shadow"][:, 0][hit] >> 1).any(), "the scene should have occluded point-light shadow rays"
 
 
+@pytest.mark.parametrize("name,depth,materials", [("materials", 8, True), ("materials", 1, False), ("box_glb", 5, True), ("multi", 4, True)])
+def test_point_shadow_packets_match_oracle_bitexact(name, depth, materials):
+    """The packet kernel's point-light passes (k_trace_packet<SHADOW_PT>: the first shadow launch when packet traversal is in
+    use) forced on, with waves of 64 different pixels -- the least coherent input it can get."""
+    _compare(SCENES[name](), 176, 128, 3, depth, materials, True, extra=dict(refillMode=2))
+
+
+def test_points_only_shadowed_by_packets():
+    base = scenes.materials_scene()
+    spec = scenes.SceneSpec("points_only", base.meshes, base.camera, dir_lights=[], point_lights=base.point_lights)
+    _compare(spec, 160, 120, 2, 6, True, True, extra=dict(refillMode=2))
+
+
 def test_points_only_shadowed():
     """No directional light: every shadow ray is a point-light ray (the SHADOW_PT launch starts at a point light)."""
     base = scenes.materials_scene()
