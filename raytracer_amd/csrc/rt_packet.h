@@ -30,6 +30,15 @@ __device__ __forceinline__ void laneStackWrite(uint32_t& reg, uint32_t value, ui
                : "+v"(reg), "=&s"(keepM0)
                : "s"(__builtin_amdgcn_readfirstlane(value)), "s"(__builtin_amdgcn_readfirstlane(index)));
 }
+// one stack entry = three words (reference, lane mask low / high) at the same lane index: M0 is set once for the three writes
+__device__ __forceinline__ void laneStackPush(uint32_t& regRef, uint32_t& regLo, uint32_t& regHi, uint32_t ref, uint64_t mask, uint32_t index)
+{
+  uint32_t keepM0;
+  asm volatile("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0\n\ts_mov_b32 m0, %3"
+               : "+v"(regRef), "+v"(regLo), "+v"(regHi), "=&s"(keepM0)
+               : "s"(__builtin_amdgcn_readfirstlane(ref)), "s"(__builtin_amdgcn_readfirstlane((uint32_t)mask)),
+                 "s"(__builtin_amdgcn_readfirstlane((uint32_t)(mask >> 32))), "s"(__builtin_amdgcn_readfirstlane(index)));
+}
 __device__ __forceinline__ uint32_t laneStackRead(uint32_t reg, uint32_t index) { return (uint32_t)__builtin_amdgcn_readlane((int)reg, (int)index); }
 // Lane masks without vector instructions.  The compiler turns `__ballot(a <= b)` into compare + select + compare and a per-lane
 // `(mask >> lane) & 1` into two ANDs and a 64-bit compare -- 11 of a node visit's ~75 vector instructions, in a kernel whose
@@ -304,17 +313,17 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
               // the farther ones go on the stack, farthest first
               if (k3 != 0xffffffffu)
               {
-                laneStackWrite(stackRef, r3, sp), laneStackWrite(stackLo, (uint32_t)m3, sp), laneStackWrite(stackHi, (uint32_t)(m3 >> 32), sp);
+                laneStackPush(stackRef, stackLo, stackHi, r3, m3, sp);
                 sp++;
               }
               if (k2 != 0xffffffffu)
               {
-                laneStackWrite(stackRef, r2, sp), laneStackWrite(stackLo, (uint32_t)m2, sp), laneStackWrite(stackHi, (uint32_t)(m2 >> 32), sp);
+                laneStackPush(stackRef, stackLo, stackHi, r2, m2, sp);
                 sp++;
               }
               if (k1 != 0xffffffffu)
               {
-                laneStackWrite(stackRef, r1, sp), laneStackWrite(stackLo, (uint32_t)m1, sp), laneStackWrite(stackHi, (uint32_t)(m1 >> 32), sp);
+                laneStackPush(stackRef, stackLo, stackHi, r1, m1, sp);
                 sp++;
               }
               if (k0 != 0xffffffffu)
