@@ -22,15 +22,8 @@ __device__ __forceinline__ float4 recordQuarter(const record16& r, int q)
 
 // A wave-wide stack held in one VGPR per word: entry i lives in lane i (v_writelane / v_readlane), so a push or a pop is one
 // instruction per word, costs no LDS and -- unlike the per-lane stacks of k_trace -- is shared by the 64 rays.
-__device__ __forceinline__ void laneStackWrite(uint32_t& reg, uint32_t value, uint32_t index)
-{
-  // (two different SGPR operands would break the constant-bus limit, so the lane select goes through M0, which is put back)
-  uint32_t keepM0;
-  asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
-               : "+v"(reg), "=&s"(keepM0)
-               : "s"(__builtin_amdgcn_readfirstlane(value)), "s"(__builtin_amdgcn_readfirstlane(index)));
-}
-// one stack entry = three words (reference, lane mask low / high) at the same lane index: M0 is set once for the three writes
+// One stack entry = three words (reference, lane mask low / high) at the same lane index.  (v_writelane with two different SGPR
+// operands would break the constant-bus limit, so the lane select goes through M0 -- set once for the three writes and put back.)
 __device__ __forceinline__ void laneStackPush(uint32_t& regRef, uint32_t& regLo, uint32_t& regHi, uint32_t ref, uint64_t mask, uint32_t index)
 {
   uint32_t keepM0;
@@ -86,7 +79,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
   const uint32_t chunksPerShard = ((total + kFetchShards - 1) / kFetchShards + chunkLen - 1) / chunkLen;
   uint32_t shardsDone = 0;
   uint32_t nRays = 0, nNodes = 0, nTris = 0, nNodeSteps = 0, nLeafSteps = 0, nFetched = 0; // nFetched: records loaded by the wave
-  uint32_t stackRef = 0, stackLo = 0, stackHi = 0; // the wave stack (see laneStackWrite)
+  uint32_t stackRef = 0, stackLo = 0, stackHi = 0; // the wave stack (see laneStackPush)
 
   while (shardsDone < kFetchShards)
   {
