@@ -1782,6 +1782,11 @@ int rthip_gather(rthip_ctx* c, float* recvDev, uint64_t floatsPerRank, int root)
   if (r != ncclSuccess)
     return commFail(r, "ncclSend/ncclRecv");
   NCCLCHK(rEnd, "ncclGroupEnd");
+  // The send reads the accumulator: a frame queued right behind this one may run its first accumulate on the other slot's
+  // stream, so that launch is made to wait for the transfer the way it waits for the previous batch's accumulate.
+  HIPCHK(hipEventRecord(c->evDone, c->stream));
+  c->lastAcc = c->evDone;
+  c->lastAccStream = c->stream;
   return 0; // queued on the context's stream: rthip_untile / rthip_synchronize order themselves behind it
 }
 
