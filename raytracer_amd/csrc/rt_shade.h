@@ -87,18 +87,32 @@ __global__ __launch_bounds__(kBlock, 8) void k_shade(ShadeArgs a)
   {
     uint32_t kept = 0; // wave-uniform
     const uint32_t runBegin = run * runLen, runEnd = min(total, runBegin + runLen);
-    for (uint32_t base = runBegin; base < runEnd; base += 64)
+    uint32_t count = runEnd - runBegin;
+    if (!SPARSE)
     {
-    const uint32_t item = base + lane;
-    bool mine = item < runEnd;
-    uint32_t p = item;
-    if (SPARSE)
-    {
-      if (mine)
-        p = a.list[item];
+      // depth 0: only the slots whose camera ray hit something are shaded (the fused primary kernels write the depth-0 bytes:
+      // 0 = hit, kDeadZero = miss).  They are gathered first, so that the shading below runs on full waves whatever the share
+      // of hits (hf10m: 52 %).  The survivors go back into the same buffer: entry k is written only after the group that
+      // holds entry k has been read (kept <= entries read so far; LDS operations of one wave complete in order).
+      uint32_t numHit = 0;
+      for (uint32_t base = runBegin; base < runEnd; base += 64)
+      {
+        const uint32_t item = base + lane;
+        const bool isHit = item < runEnd && a.pb.live[item] == depthTag;
+        const uint64_t m = __ballot(isHit);
+        if (isHit)
+          keep[numHit + rankIn(m)] = item;
+        numHit += (uint32_t)__popcll(m);
+      }
+      count = numHit;
     }
-    else if (mine)
-      mine = a.pb.live[p] == depthTag; // (the fused primary kernels write the depth-0 bytes: 0 = hit, kDeadZero = miss)
+    for (uint32_t base = 0; base < count; base += 64)
+    {
+    const uint32_t idx = base + lane;
+    const bool mine = idx < count;
+    uint32_t p = 0;
+    if (mine)
+      p = SPARSE ? a.list[runBegin + idx] : keep[idx];
     bool survives = false;
     if (mine)
     {
