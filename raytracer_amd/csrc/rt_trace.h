@@ -454,7 +454,8 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 4)) void k_tra
       const bool atNode = active && !needPop && (int)cur >= 0;
       const bool stalled = active && !needPop && postponed != kNone && !((int)cur >= 0);
       const uint64_t nodeMask = __ballot(atNode || (active && needPop));
-      const uint32_t numStalled = __popcll(__ballot(stalled));
+      const uint64_t stalledMask = __ballot(stalled);
+      const uint32_t numStalled = __popcll(stalledMask);
       // A leaf step costs as much as two node steps whatever the number of lanes that take part.  Coherent rays reach their
       // leaves within a step or two of each other, so it pays to let the waiting lanes pile up (hf10m at 64 spp: -6 % frame
       // time with 24 instead of 4); incoherent rays trickle in one by one and waiting only idles lanes (1M soup: +18 %).
@@ -552,7 +553,8 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 4)) void k_tra
       // lanes out of step for good (hf10m at 64 spp: -10 % frame time with 56 instead of 16, the bunny -11 %); incoherent
       // ones finish one by one and waiting only idles lanes (1M soup: +20 % with 56, +39 % with whole groups).  The host
       // measures which way a scene leans (rthip.hip: calibrateRefill).
-      if (refillPossible && (uint32_t)__popcll(__ballot(!active)) >= a.refillAt)
+      // (an active lane is at a node, needs a pop or waits on a leaf: the idle ones are the rest -- no third ballot)
+      if (refillPossible && 64u - (uint32_t)__popcll(nodeMask | stalledMask) >= a.refillAt)
         break;
       // --- NODE step: one 64-byte node = four quantised child boxes
       if (COUNT)
