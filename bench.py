@@ -10,6 +10,9 @@ N > 1 the SAME frame is split by 64x64 tiles dealt round-robin to the ranks and 
 so the scaling is "strong".  value = rays cast by all ranks per frame / wall time per frame.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hf10m|soup1m|cube|bunny|hf8k|...]
+
+With --gpus N > 1 and no launcher around it (WORLD_SIZE unset) the script starts its own N ranks, one per GPU
+(raytracer_amd/dist.py launch_ranks); under `python -m torch.distributed.run` it is one of the ranks.
 """
 import argparse
 import json
@@ -29,10 +32,30 @@ VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # 1228.8 G wave64 VALU instructions per s
 
 
 def cpu_workers():
-    """The reference's worker count, hardware_concurrency() - 2 (ThreadPool.h:29), on the cores this job may use: the GPU
-    box hands a one-GPU job 16 of the machine's cores."""
-    cores = min(os.cpu_count() or 16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 16, 16)
-    return max(1, cores - 2), cores
+    """The reference's worker count, hardware_concurrency() - 2 (ThreadPool.h:29), on the cores this job may use: the
+    smallest of the affinity mask, the cgroup CPU quota and the share the harness announces (OMP_NUM_THREADS; the GPU box
+    shows every core of the machine to a job that owns 16 of them).  RT_CPU_CORES overrides.  Returns (workers, cores, source)."""
+    limits = {}
+    if hasattr(os, "sched_getaffinity"):
+        limits["affinity mask"] = len(os.sched_getaffinity(0))
+    else:
+        limits["cpu_count"] = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            limits["cgroup cpu.max"] = max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    for var in ("RT_CPU_CORES", "OMP_NUM_THREADS"):
+        v = os.environ.get(var, "")
+        if v.isdigit() and int(v) > 0:
+            if var == "RT_CPU_CORES":
+                limits = {var: int(v)}
+                break
+            limits[var] = int(v)
+    source = min(limits, key=limits.get)
+    cores = limits[source]
+    return max(1, cores - 2), cores, source
 
 
 def workloads():
@@ -144,7 +167,7 @@ def roofline_block(workload, ktimes, wc, spp, ktimes_alone=None, scene_bytes=Non
 def cpu_baseline(spec, wl, flat, seconds):
     """The oracle (restated src/cpu ThreadPool path) on this box's host cores, on a bounded sample of the same workload."""
     from tests import scenes as oracle_side  # the checker / baseline (imports oracle/), never the thing measured above
-    workers, cores = cpu_workers()
+    workers, cores, cores_source = cpu_workers()
     spec.__class__ = oracle_side.SceneSpec
     oracle = spec.build_oracle()
     bw, bh, spp, max_depth = wl["width"], wl["height"], wl["spp"], wl["max_depth"]
@@ -174,7 +197,7 @@ def cpu_baseline(spec, wl, flat, seconds):
         sample = f"1 sample pass of the centre {win[2] - win[0]}x{win[3] - win[1]} window of the {bw}x{bh} frame, timed {reps}x"
     oc = res["counters"]
     cpu_rays = oc["extendPrimary"] + oc["extendSecondary"] + oc["shadow"]
-    return {"value": round(cpu_rays / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": workers, "host_cores_available": cores, "kind": "port",
+    return {"value": round(cpu_rays / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": workers, "host_cores_available": cores, "host_cores_source": cores_source, "kind": "port",
             "sample": sample + (" (variant B: CPU walk of the same flattened BVH)" if wl["flat_cpu"] else
                                 " (variant A: reference-faithful model tree + linear triangle scan)") +
             f", ThreadPool restatement with {workers} workers (hardware_concurrency()-2 of the {cores} cores this job may use), g++ -O2 -ffp-contract=off",
@@ -194,6 +217,19 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the bounded CPU-baseline sample")
     ap.add_argument("--torch-gather", action="store_true", help="N>1: gather with torch.distributed instead of rthip_gather (the C ABI's RCCL gather)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: this process becomes the launcher (it touches no GPU) and starts N fresh
+        # ranks of this same script, one per GPU, exactly as `python -m torch.distributed.run --nproc-per-node N` would
+        from raytracer_amd import dist as rdist
+        try:
+            rc, text = rdist.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                          backend=os.environ.get("RT_DIST_BACKEND", "nccl"))
+        except RuntimeError as e:
+            raise SystemExit("bench.py: %s" % e)
+        sys.stdout.write(text)
+        sys.stdout.flush()
+        raise SystemExit(rc)
 
     import torch
     import torch.distributed as dist

@@ -216,7 +216,8 @@ int rthip_probe_trace(rthip_ctx* ctx, const float* origin3, const float* dir3, u
                       uint32_t* triIdOut, float* tOut, uint8_t* anyOut);
 
 /* Allocation-free variant of rthip_probe_trace.  It has NO counterpart in the reference; it exists for callers that cannot
- * allocate: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels and results
+ * allocate: tight serving loops, harnesses that forbid hipMalloc.  (It is NOT capturable into a HIP graph: it selects the
+ * context's device, works on the context's own stream and returns only after hipStreamSynchronize.)  Same kernels and results
  * as rthip_probe_trace, but every pointer is DEVICE memory on the context's GPU (origins / directions: 3 floats per ray;
  * outputs: n entries each) and all working memory (ray and hit records, liveness bytes, work counters, traversal-stack
  * spill) lives in a static device array of about 6.3 MiB that each GPU the library runs on holds until the process ends.

@@ -1147,9 +1147,19 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
       (rc = codesSorted.ensure(largest)) || (rc = ids.ensure(largest)) || (rc = idsSorted.ensure(largest)) || (rc = binary.ensure(largest)) ||
       (rc = done.ensure(largest)) || (rc = frontier.ensure(2 * (size_t)largest)) || (rc = small.ensure(2 + kLevels + 2)))
     return rc;
+  // temporary storage of the radix sort: rocPRIM picks its algorithm by size, so the requirement is asked for every model
+  // size that will be sorted and the largest answer is allocated (not assumed monotone in n)
   size_t sortBytes = 0;
-  if (rocprim::radix_sort_pairs(nullptr, sortBytes, codes.p, codesSorted.p, ids.p, idsSorted.p, largest, 0, 64, c->stream) != hipSuccess)
-    return RTHIP_E_ARG;
+  for (uint32_t k = 0; k < info->numModelNodes; ++k)
+  {
+    const uint32_t n = modelNodes[k].triCount;
+    if (n <= maxLeaf)
+      continue;
+    size_t need = 0;
+    if (rocprim::radix_sort_pairs(nullptr, need, codes.p, codesSorted.p, ids.p, idsSorted.p, n, 0, 64, c->stream) != hipSuccess)
+      return RTHIP_E_ARG;
+    sortBytes = std::max(sortBytes, need);
+  }
   if ((rc = sortTemp.ensure(sortBytes)))
     return rc;
   HIPCHK(hipMemcpy(trisIn.p, trisModelOrder, sizeof(rtflat_tri) * numTris, hipMemcpyHostToDevice));
@@ -1174,7 +1184,8 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
     const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
     hipLaunchKernelGGL(k_lbvh_prims, grid, block, 0, c->stream, trisIn.p + base, n, info->padAbs, sceneLo, sceneInvExt, primBoxes.p, codes.p, ids.p);
     HIPCHK(hipGetLastError());
-    if (rocprim::radix_sort_pairs(sortTemp.p, sortBytes, codes.p, codesSorted.p, ids.p, idsSorted.p, n, 0, 64, c->stream) != hipSuccess)
+    size_t sortBytesNow = sortBytes; // (rocPRIM takes the size by reference)
+    if (rocprim::radix_sort_pairs(sortTemp.p, sortBytesNow, codes.p, codesSorted.p, ids.p, idsSorted.p, n, 0, 64, c->stream) != hipSuccess)
       return RTHIP_E_ARG;
     hipLaunchKernelGGL(k_lbvh_topology, grid, block, 0, c->stream, codesSorted.p, n, binary.p);
     HIPCHK(hipGetLastError());
@@ -1256,6 +1267,15 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
   HIPCHK(hipMemcpy(c->modelNodes.p, modelNodes, sizeof(rtflat_model_node) * info->numModelNodes, hipMemcpyHostToDevice));
   if (int rcLights = uploadLights(c, dirLights, numDirLights, pointLights, numPointLights))
     return rcLights;
+  if ((size_t)nodesUsed * 2 < c->nodes.n)
+  {
+    // the node array was sized for the worst case (one node per triangle); keep what the tree uses
+    DevBuf<rtflat_node> tight;
+    if ((rc = tight.ensure(nodesUsed)))
+      return rc;
+    HIPCHK(hipMemcpy(tight.p, c->nodes.p, sizeof(rtflat_node) * nodesUsed, hipMemcpyDeviceToDevice));
+    c->nodes = std::move(tight);
+  }
   info->numNodes = nodesUsed;
   info->maxDepthBlas = deepest;
   c->info = *info;
@@ -2033,8 +2053,18 @@ int rthip_trace_rays_static(rthip_ctx* c, const float* originDev3, const float* 
     rthip_ctx* c;
     uint32_t cursor;
     bool timing;
-    ~Restore() { c->fetchCursor = cursor, c->kernelTiming = timing; }
-  } restore{c, keepCursor, keepTiming};
+    uint32_t launches[6];
+    // (the kernel timer counts launches per family even when it records no events: a call in the middle of a frame must
+    // leave what rthip_get_kernel_times reports for that frame alone)
+    ~Restore()
+    {
+      c->fetchCursor = cursor, c->kernelTiming = timing;
+      for (int k = 0; k < 6; ++k)
+        c->kernelLaunches[k] = launches[k];
+    }
+  } restore{c, keepCursor, keepTiming, {}};
+  for (int k = 0; k < 6; ++k)
+    restore.launches[k] = c->kernelLaunches[k];
   // the array keeps the previous call's contents: counters and work-fetch cursors must start at zero; ray records, hit
   // records and liveness bytes of the n slots in use are all rewritten below before anything reads them
   HIPCHK(hipMemsetAsync(c->fetch.p, 0, kStaticFetchWords * sizeof(uint32_t), c->stream));

@@ -5,7 +5,77 @@ A path depends only on (w, h, samp), the camera and the scene (src/cpu/CPURender
 exchange anything while rendering; per-pixel accumulation over `samp` stays inside one rank, which keeps the
 assembled image bit-identical to a single-GPU render.
 """
+import os
+import socket
+import subprocess
+import sys
+
 import numpy as np
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Self-launch: `python bench.py --gpus N` with no launcher around it (the reference is one process, src/main.cpp:6-56; here
+# one process per GPU).  The parent touches no GPU: it only starts N fresh children with the torch.distributed environment
+# (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), waits for them, relays rank 0's stdout and fails if any failed.
+
+def free_port(host="127.0.0.1"):
+    with socket.socket() as s:
+        s.bind((host, 0))
+        return s.getsockname()[1]
+
+
+def rank_env(rank, world_size, port, base=None, host="127.0.0.1"):
+    """Environment of rank `rank` of a one-node job of `world_size` processes (what torch.distributed.run would set)."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world_size), LOCAL_WORLD_SIZE=str(world_size),
+               MASTER_ADDR=host, MASTER_PORT=str(port), RT_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    return env
+
+
+def visible_gpus():
+    """Number of GPUs this process may use, counted without initialising one (the launcher parent must stay GPU-free)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def launch_ranks(argv, world_size, backend="nccl", devices=None, timeout=None):
+    """Starts `argv` (a command line, e.g. [sys.executable, 'bench.py', ...]) once per rank, waits for all of them and returns
+    (exit code, rank 0's stdout).  A rank that fails takes the others down (they would wait in a collective for ever).
+    With `nccl` every rank needs a GPU of its own: more ranks than visible devices is an error, not a silent single-GPU
+    run; `gloo` rehearsals may share devices."""
+    if world_size < 1:
+        raise ValueError("world_size must be >= 1")
+    if backend == "nccl":
+        have = visible_gpus() if devices is None else int(devices)
+        if world_size > have:
+            raise RuntimeError("--gpus %d asked for but only %d GPU(s) are visible: one rank per GPU over RCCL "
+                               "(RT_DIST_BACKEND=gloo rehearses N ranks on fewer devices)" % (world_size, have))
+    port = free_port()
+    procs = []
+    for rank in range(world_size):
+        out = subprocess.PIPE if rank == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen(list(argv), env=rank_env(rank, world_size, port), stdout=out, stderr=None))
+    failed = 0
+    text = ""
+    try:
+        # rank 0 is the only one that prints; reading it to the end also waits for it
+        text = procs[0].communicate(timeout=timeout)[0].decode("utf-8", "replace")
+        for p in procs:
+            rc = p.wait(timeout=timeout)
+            failed = failed or rc
+    except subprocess.TimeoutExpired:
+        failed = 124
+    finally:
+        for p in procs:  # exactly the children started above, by handle
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return (failed if failed else 0), text
 
 
 def tile_grid(width, height, tile_size=64):

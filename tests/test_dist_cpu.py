@@ -138,3 +138,47 @@ def test_tile_queue_single_process_hands_out_every_tile_once():
     while (b := q.next_batch()) is not None:
         got.append(b.tolist())
     assert got == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10]]
+
+
+# ---- the self-launcher behind `python bench.py --gpus N` (raytracer_amd/dist.py launch_ranks)
+_CHILD = """
+import json, os, sys
+keys = ["RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "RT_SELF_LAUNCHED", "HSA_ENABLE_IPC_MODE_LEGACY"]
+rec = {k: os.environ.get(k) for k in keys}
+open(os.path.join(sys.argv[1], "rank%s.json" % rec["RANK"]), "w").write(json.dumps(rec))
+print("noise from rank", rec["RANK"])          # only rank 0's stdout may reach the caller
+if rec["RANK"] == "0":
+    print(json.dumps({"n_gpus": int(rec["WORLD_SIZE"])}))
+sys.exit(int(sys.argv[2]) if rec["RANK"] == sys.argv[3] else 0)
+"""
+
+
+def test_launcher_starts_one_rank_per_gpu_with_the_distributed_environment(tmp_path):
+    import json
+    rc, text = rdist.launch_ranks([sys.executable, "-c", _CHILD, str(tmp_path), "0", "-1"], 3, backend="gloo", timeout=120)
+    assert rc == 0
+    lines = text.strip().splitlines()
+    assert lines[0] == "noise from rank 0" and json.loads(lines[-1]) == {"n_gpus": 3} and len(lines) == 2
+    recs = [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(3)]
+    assert [r["RANK"] for r in recs] == ["0", "1", "2"] and [r["LOCAL_RANK"] for r in recs] == ["0", "1", "2"]
+    assert {r["WORLD_SIZE"] for r in recs} == {"3"} and {r["MASTER_ADDR"] for r in recs} == {"127.0.0.1"}
+    assert len({r["MASTER_PORT"] for r in recs}) == 1 and int(recs[0]["MASTER_PORT"]) > 0
+    assert {r["HSA_ENABLE_IPC_MODE_LEGACY"] for r in recs} == {"0"}
+
+
+def test_launcher_fails_when_a_rank_fails_and_refuses_more_ranks_than_gpus(tmp_path):
+    rc, _ = rdist.launch_ranks([sys.executable, "-c", _CHILD, str(tmp_path), "7", "1"], 2, backend="gloo", timeout=120)
+    assert rc == 7
+    with pytest.raises(RuntimeError, match="only 1 GPU"):
+        rdist.launch_ranks([sys.executable, "-c", "pass"], 2, backend="nccl", devices=1)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus 2` on a box with fewer GPUs must say so, not run on one GPU and print n_gpus: 1."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RT_DIST_BACKEND")}
+    import torch
+    if torch.cuda.device_count() >= 64:
+        pytest.skip("more GPUs than the test asks for")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "GPU(s) are visible" in p.stderr and p.stdout.strip() == ""

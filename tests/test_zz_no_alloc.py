@@ -32,8 +32,11 @@ def _static_trace(ctx, org, d, tmin=1e-4, tmax=1e20):
     t_t = torch.full((n,), -1.0, dtype=torch.float32, device=dev)
     any_t = torch.full((n,), 77, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info(dev)  # hipMemGetInfo: the call must leave the device's free memory as it found it
     rc = ra.capi.hip_lib().rthip_trace_rays_static(ctx, o_t.data_ptr(), d_t.data_ptr(), n, float(np.float32(tmin)), float(np.float32(tmax)),
                                                    tri_t.data_ptr(), t_t.data_ptr(), any_t.data_ptr())
+    free_after, _ = torch.cuda.mem_get_info(dev)
+    assert free_after == free_before, "rthip_trace_rays_static changed the device's free memory: %d -> %d" % (free_before, free_after)
     return rc, tri_t.cpu().numpy().view(np.uint32), t_t.cpu().numpy(), any_t.cpu().numpy()
 
 
@@ -69,8 +72,10 @@ def test_static_entry_point_rejects_sizes_beyond_its_limit_and_leaves_frames_alo
     assert hl.rthip_trace_rays_static(r.context, None, None, 4, 0.0, 1.0, None, None, None) == ra.capi.RTHIP_E_ARG
     # a call in the middle of a frame does not disturb it (the context's own buffers are untouched)
     org, d = _rays(500, 6)
+    launches_before = r.kernel_times()
     rc, tri, t, anyh = _static_trace(r.context, org, d)
     assert rc == 0
+    assert {k: v[1] for k, v in r.kernel_times().items()} == {k: v[1] for k, v in launches_before.items()}  # launch tallies of the frame untouched
     r.render_passes(1, 1)
     got = r.accumulator()
     ref = spec.build_product(options=dict(maxDepth=3))
