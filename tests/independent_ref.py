@@ -15,7 +15,11 @@ Everything is vectorised over rays x triangles with numpy float32 arrays: each n
 the scalar C++ (no FMA contraction), so the results can be compared bit for bit.  glm orders used (glm 0.9.9 / 1.0 scalar
 paths): dot = (x*x' + y*y') + z*z'; cross = (a.y*b.z - b.y*a.z, a.z*b.x - b.z*a.x, a.x*b.y - b.x*a.y); normalize = v *
 (1 / sqrt(dot(v, v))); mat4 * vec4 = (m0*x + m1*y) + (m2*z + m3*w); min(a, b) = b < a ? b : a; max(a, b) = a < b ? b : a.
-Only depth 0 is evaluated (primary hit, its shadow rays, its lights): what a render with a depth cap of 1 accumulates."""
+render_first_hit evaluates depth 0 only (primary hit, its shadow rays, its lights: what a depth cap of 1 accumulates);
+render_paths follows whole paths (src/cpu/CPUScene.cpp:6-65: roulette, emissive / throughput order, lights per depth, the
+cosine-weighted bounce with its double-precision islands, the depth cap) and sums passes in `samp` order
+(src/cpu/CPURenderer.cpp:196-197).  Its sin / cos are numpy's float64 functions rounded once to fp32 -- NOT the oracle's
+sincos_det -- so the two share no transcendental code; a pixel where that choice matters would be reported by the test."""
 import numpy as np
 
 F = np.float32
@@ -344,3 +348,93 @@ def render_first_hit(scene, cam, W, H, num_samples, samp, dir_lights, point_ligh
         shadow[hit] = bits
     tri_id = np.where(hit, tri, 0xFFFFFFFF).astype(np.uint32)
     return (radiance / F(num_samples)).reshape(H, W, 3), tri_id.reshape(H, W), shadow.reshape(H, W), t.reshape(H, W)
+
+
+def bounce_directions(normal_light, rnd):
+    """CPUScene.cpp:54-60.  r1 is a double product narrowed to float (:54); |w.x| > 0.1 compares against a double literal (:58);
+    cos / sin are the float overloads the file needs to compile at all: here float64 libm rounded once."""
+    r1 = (2.0 * np.pi * rnd[:, 0].astype(np.float64)).astype(F)
+    r2 = rnd[:, 1]
+    r2s = np.sqrt(r2)
+    w = normal_light
+    pick_y = np.abs(w[:, 0]).astype(np.float64) > 0.1
+    axis = np.where(pick_y[:, None], np.array([0, 1, 0], F), np.array([1, 0, 0], F))
+    u = normalize(cross(axis, w))
+    v = cross(w, u)
+    c = np.cos(r1.astype(np.float64)).astype(F)
+    sn = np.sin(r1.astype(np.float64)).astype(F)
+    return normalize(((u * c[:, None]) * r2s[:, None] + (v * sn[:, None]) * r2s[:, None]) + w * np.sqrt(F(1) - r2)[:, None])
+
+
+def render_paths(scene, cam, W, H, num_samples, samp, dir_lights, point_lights, max_depth=12, materials=False, point_shadows=False):
+    """One sample pass of whole paths (traceRay, CPUScene.cpp:6-65, unrolled from its tail recursion).  Returns the pass's
+    accumulator contribution radiance / N (H, W, 3), and per depth the hit ids (D, H, W) and shadow bits (D, H, W; 0xFF where
+    the path has no hit at that depth)."""
+    o, d, rnd = primary_rays(cam, W, H, samp)
+    o, d, rnd = np.broadcast_to(o, d.shape).reshape(-1, 3).astype(F), d.reshape(-1, 3), rnd.reshape(-1, 3)
+    R = W * H
+    radiance = np.zeros((R, 3), F)     # payload.accumulatedRadiance
+    material = np.ones((R, 3), F)      # payload.accumulatedMaterial
+    emissive_on = F(1.0)               # payload.emissive: 1 for the camera ray's hit, 0 afterwards (:61)
+    alive = np.arange(R)
+    tri_aov = np.full((max_depth, R), 0xFFFFFFFF, np.uint32)
+    shadow_aov = np.full((max_depth, R), 0xFF, np.uint8)
+    for depth in range(max_depth):     # :15: a path that reaches depth 12 returns before adding anything
+        if alive.size == 0:
+            break
+        t, tri = scene.closest(o, d)
+        hit = t < FMAX                 # :10
+        alive, o, d, rnd_a, t, tri = alive[hit], o[hit], d[hit], rnd[alive[hit]], t[hit], tri[hit]
+        if alive.size == 0:
+            break
+        n = scene.normal_pool[tri]
+        albedo = np.tile(np.array([0, 1, 0], F), (len(t), 1))   # :245-246
+        emissive = np.zeros((len(t), 3), F)
+        if materials:
+            albedo, emissive = scene.evaluate_materials(tri, scene.hit_texcoords(tri, o, d))
+        # :13-25 roulette (only beyond depth 5); p = max(max(x, y), z) with std::max's a < b ? b : a
+        p = vmax(vmax(albedo[:, 0], albedo[:, 1]), albedo[:, 2])
+        if depth > 5:
+            keep = ~(rnd_a[:, 2] >= p)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                material[alive[keep]] = material[alive[keep]] / p[keep, None]
+            alive, o, d, rnd_a, t, tri, n, albedo, emissive = (x[keep] for x in (alive, o, d, rnd_a, t, tri, n, albedo, emissive))
+            if alive.size == 0:
+                break
+        tri_aov[depth, alive] = tri   # (AOV convention shared with the oracle and the device: hits that get shaded)
+        pos = o + d * t[:, None]       # :238
+        rad = radiance[alive]
+        mat = material[alive]
+        rad = rad + (mat * emissive) * emissive_on   # :27
+        mat = mat * albedo                           # :28
+        bits = np.zeros(len(t), np.uint8)
+        for l, (ldir, lcol) in enumerate(dir_lights):  # :31-38
+            ldir, lcol = np.asarray(ldir, F), np.asarray(lcol, F)
+            occ = scene.occluded(pos, np.broadcast_to(-ldir, pos.shape).astype(F))
+            bits |= (occ.astype(np.uint8) << l)
+            diffuse = vmax(dot(n, -ldir), F(0.0))
+            e = (albedo * diffuse[:, None]) * lcol + F(0.03)   # BRDF.cpp:8,12 (unflipped normal, no throughput factor)
+            rad = np.where(occ[:, None], rad, rad + e)
+        for l, (lpos, lcol, att) in enumerate(point_lights):   # :39-49
+            lpos, lcol = np.asarray(lpos, F), np.asarray(lcol, F)
+            ldir = lpos - pos
+            dist = np.sqrt(dot(ldir, ldir))
+            illum = vmax(F(1) - dist / F(att), F(0.0))
+            diffuse = vmax(dot(n, ldir), F(0.0))
+            e = (albedo * diffuse[:, None]) * lcol + F(0.03)
+            if point_shadows:  # Compute.metal:238-254
+                occ = scene.occluded((pos + n * F(1e-3)).astype(F), ldir.astype(F), tmin=F(0.0), tmax=F(1.0))
+                bits |= (occ.astype(np.uint8) << (len(dir_lights) + l))
+                rad = np.where(occ[:, None], rad, rad + illum[:, None] * e)
+            else:
+                rad = rad + illum[:, None] * e
+        shadow_aov[depth, alive] = bits
+        radiance[alive] = rad
+        material[alive] = mat
+        # :54-63 the bounce: origin = hit position (no offset), same rnd01 at every depth
+        with np.errstate(invalid="ignore"):
+            normal_light = np.where((dot(n, d) < 0)[:, None], n, -n)   # :240
+        d = bounce_directions(normal_light, rnd_a).astype(F)
+        o = pos.astype(F)
+        emissive_on = F(0.0)
+    return ((radiance / F(num_samples)).reshape(H, W, 3), tri_aov.reshape(max_depth, H, W), shadow_aov.reshape(max_depth, H, W))
