@@ -82,13 +82,38 @@ KERNEL_NAMES = {"extend": "k_trace<PRIMARY|CLOSEST> / k_trace_packet<PRIMARY> (e
                 "accumulate": "k_accumulate"}
 
 
+def kernel_sources_sha16():
+    """Fingerprint of the device code the library was built from (the kernel headers, rthip.hip and the Makefile's flags):
+    profiles/traffic.json is stamped with it when the counters are collected, so a replayed counter set that no longer
+    belongs to the kernels being benched is called out (the GPU box has no .git to ask)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    base = os.path.join(ROOT, "raytracer_amd")
+    for path in sorted(glob.glob(os.path.join(base, "csrc", "*"))) + [os.path.join(base, "Makefile")]:
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+FP32_PEAK_TFLOPS = 256 * 4 * 64 * 2 * 2.4e9 / 2.0 / 1e12  # 157.3: one wave64 FMA (128 flop) per SIMD every 2 clocks
+
+
 def roofline_block(workload, ktimes, wc, spp, ktimes_alone=None, scene_bytes=None):
-    """roofline of the dominant kernel family.  `achieved` is ALGORITHMIC bytes per launch / average launch duration
-    (per ray 32 B ray record + 16 B hit record (any-hit: 4) + 64 B per node and per triangle record the
-    launch fetches, counted by the device: a per-lane launch fetches every record a ray visits, a packet launch fetches a
-    record once for the 64 rays of a wave).  Next to it: the HBM bytes the counters saw (profiles/traffic.json, from rocprofv3 --pmc passes
-    of this same command, FETCH_SIZE x2 + WRITE_SIZE) and the VALU issue rate, each against its own peak; `bound` names the
-    ceiling the kernel is closest to, by that evidence (None when no counter data exists for the workload)."""
+    """Roofline of the dominant kernel family, against the bound it actually runs into.
+
+    The traversal kernels are VALU-bound: `bound` = "valu", `achieved` = wave64 VALU instructions
+    issued per second by the family's launches (SQ_INSTS_VALU per launch, from the rocprofv3 --pmc passes of this same
+    command in profiles/traffic.json, divided by the launch duration measured live here), `peak` = 256 CUs x 4 SIMDs x 2.4 GHz
+    / 2 clocks per instruction, `frac` = achieved / peak.  Beside it:
+      fp32       SURVEY.md 8(d)'s flop figure: 27 flop per box test x 4 boxes per wide node + 57 per triangle test, over the
+                 nodes / triangles the family's rays algorithmically visit (device counters) -> achieved TFLOP/s, fraction of the
+                 fp32 vector peak, and VALU lane-operations issued per algorithmic flop (an FMA-only kernel would need 0.5);
+      algorithmic_GBps   8(d)'s byte figure (32 B ray + 16 B hit (any-hit: 4) + 64 B per record fetched) / launch duration: mostly
+                 cache hits, so it carries no fraction of the HBM peak;
+      traffic / hbm_counters   HBM bytes per launch by the counters (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 corrections).
+    A family with no counter data, or one the counters show closer to the HBM ceiling (k_shade when it dominates), is reported
+    the contract's way: bound "hbm", achieved = algorithmic GB/s."""
     n_ext = wc["extendPrimary"] + wc["extendSecondary"]
     n_paths = wc["extendPrimary"]
     alg_bytes = {
@@ -100,6 +125,11 @@ def roofline_block(workload, ktimes, wc, spp, ktimes_alone=None, scene_bytes=Non
         "shade": (32.0 + 16.0 + 32.0) * n_ext,                # ray + hit read, next ray written, per shaded ray
         "accumulate": 24.0 * n_paths / spp + 17.0 * n_paths,  # accumulator read+write per pixel + radiance and liveness byte per sample
     }
+    # 8(d): slab test ~27 flop per box (a wide node holds four), triangle test ~57
+    alg_flops = {
+        "extend": 108.0 * wc["nodesVisitedExtend"] + 57.0 * wc["trisTestedExtend"],
+        "shadow": 108.0 * (wc["nodesVisited"] - wc["nodesVisitedExtend"]) + 57.0 * (wc["trisTested"] - wc["trisTestedExtend"]),
+    }
     ktimes = {k: v for k, v in ktimes.items() if k in alg_bytes}
     # the dominant family is the one that takes longest when every kernel has the GPU to itself: durations measured while
     # batches overlap are stretched by whatever ran beside them, which makes two families of similar weight trade places
@@ -107,61 +137,95 @@ def roofline_block(workload, ktimes, wc, spp, ktimes_alone=None, scene_bytes=Non
     dominant = max(rank, key=lambda k: rank[k][0])
     k_ms, k_launches = ktimes[dominant]
     k_s = max(k_ms * 1e-3, 1e-12)
-    achieved = alg_bytes[dominant] / k_s / 1e9
-    counters = {}
+    launch_s = k_s / max(1e-9, k_launches)
+    alg_gbps = alg_bytes[dominant] / k_s / 1e9
+    counters, stamp = {}, {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            counters = json.load(open(tpath)).get(workload, {}).get(dominant, {}) or {}
+            doc = json.load(open(tpath)).get(workload, {})
+            counters = doc.get(dominant, {}) or {}
+            stamp = doc.get("_stamp", {}) or {}
         except Exception:
             counters = {}
     if not isinstance(counters, dict):
         counters = {}
+    sha_now = kernel_sources_sha16()
+    counters_stale = None
+    if counters:
+        counters_stale = (None if stamp.get("kernel_sources_sha16") == sha_now else
+                          "counters were collected on other kernel sources (%s) than the ones benched (%s): traffic / valu figures are indicative only"
+                          % (stamp.get("kernel_sources_sha16", "unstamped"), sha_now))
     traffic = counters.get("hbm_bytes_per_launch")
     valu_insts = counters.get("valu_insts_per_launch")
-    launch_s = k_s / max(1e-9, k_launches)
     hbm_frac = (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None
-    valu_frac = (valu_insts / launch_s / 1e9 / VALU_PEAK_GINST) if valu_insts else None
-    bound = None
+    valu_ginst = (valu_insts / launch_s / 1e9) if valu_insts else None
+    valu_frac = (valu_ginst / VALU_PEAK_GINST) if valu_ginst is not None else None
+    cache_note = None
+    bound = "hbm"
     if hbm_frac is not None and valu_frac is not None:
         bound = "hbm" if hbm_frac >= valu_frac else "valu"
-    cache_note = None
-    if scene_bytes is not None and scene_bytes < 32 * 2**20:
-        # nodes + triangles fit the 32 MiB of L2: every record fetch is a cache hit, so the algorithmic figure (64 B per record
-        # visited) does not measure HBM at all and can exceed the HBM peak; the kernel is instruction-bound
+    if scene_bytes is not None and scene_bytes < 32 * 2**20 and dominant in alg_flops:
+        # nodes + triangles fit the 32 MiB of L2: every record fetch is a cache hit; the kernel is instruction-bound
         bound = "valu"
-        cache_note = "scene records (%.1f MiB) are L2-resident: `achieved` counts cache hits and is not an HBM measure" % (scene_bytes / 2**20)
+        cache_note = "scene records (%.1f MiB) are L2-resident: the algorithmic byte figure counts cache hits and is not an HBM measure" % (scene_bytes / 2**20)
+    flops = alg_flops.get(dominant)
+
+    def fp32_block(seconds):
+        if not flops:
+            return None
+        tf = flops / seconds / 1e12
+        return {"algorithmic_flops_per_launch": round(flops / max(1e-9, k_launches), 1), "achieved_TFLOPs": round(tf, 3), "peak_TFLOPs": round(FP32_PEAK_TFLOPS, 1),
+                "frac_of_fp32_peak": round(tf / FP32_PEAK_TFLOPS, 4),
+                # wave instructions x 64 lanes per algorithmic flop; 0.5 for a kernel made of nothing but full-wave FMAs
+                "lane_ops_per_algorithmic_flop": round(valu_insts * k_launches * 64.0 / flops, 3) if valu_insts else None,
+                "definition": "27 flop x 4 boxes per wide node + 57 per triangle test (SURVEY 8d), nodes / triangles from the device's counters"}
     alone = None
     if ktimes_alone and ktimes_alone.get(dominant, (0, 0))[0] > 0:
         a_ms, a_launches = ktimes_alone[dominant]
-        a_launch_s = a_ms * 1e-3 / max(1, a_launches)
-        alone = {"avg_launch_ms": round(a_ms / max(1, a_launches), 5), "achieved": round(alg_bytes[dominant] / (a_ms * 1e-3) / 1e9, 2),
-                 # (no fraction of the HBM peak for an L2-resident scene: its record fetches never reach HBM, see cache_note)
-                 "frac": None if cache_note else round(alg_bytes[dominant] / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        a_s = a_ms * 1e-3
+        a_launch_s = a_s / max(1, a_launches)
+        a_fp = fp32_block(a_s)
+        alone = {"avg_launch_ms": round(a_ms / max(1, a_launches), 5),
+                 "frac": (round(valu_insts / a_launch_s / 1e9 / VALU_PEAK_GINST, 4) if valu_insts else None) if bound == "valu"
+                 else round(alg_bytes[dominant] / a_s / 1e9 / HBM_PEAK_GBS, 4),
+                 "algorithmic_GBps": round(alg_bytes[dominant] / a_s / 1e9, 2),
                  "frac_of_hbm_peak_counters": round(traffic / a_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                  "frac_of_valu_peak": round(valu_insts / a_launch_s / 1e9 / VALU_PEAK_GINST, 4) if valu_insts else None,
+                 "frac_of_fp32_peak": a_fp["frac_of_fp32_peak"] if a_fp else None,
                  "kernel_ms_per_step": {k: round(v[0], 4) for k, v in ktimes_alone.items() if k in alg_bytes},
                  "note": "one batch at a time, one stream: every kernel has the GPU to itself"}
-    return {"bound": bound, "kernel": KERNEL_NAMES[dominant], "alone": alone, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+    if bound == "valu":
+        achieved, peak, unit = valu_ginst, VALU_PEAK_GINST, "G wave64-VALU-instr/s"
+        frac = valu_frac
+    else:
+        achieved, peak, unit = alg_gbps, HBM_PEAK_GBS, "GB/s"
+        frac = alg_gbps / HBM_PEAK_GBS if not cache_note else None
+    return {"bound": bound, "kernel": KERNEL_NAMES[dominant], "achieved": round(achieved, 2) if achieved is not None else None, "peak": peak, "unit": unit,
+            "frac": round(frac, 4) if frac is not None else None, "traffic": traffic,
+            "fp32": fp32_block(k_s), "alone": alone,
+            "algorithmic_GBps": round(alg_gbps, 2), "algorithmic_bytes_per_launch": round(alg_bytes[dominant] / max(1e-9, k_launches), 1),
             "hbm_counters": {"bytes_per_launch": traffic, "GB/s": round(traffic / launch_s / 1e9, 1) if traffic else None,
                              "frac_of_hbm_peak": round(hbm_frac, 4) if hbm_frac is not None else None,
                              "l2_hit_rate": counters.get("l2_hit_rate")},
-            "valu": {"wave_insts_per_launch": valu_insts, "Ginst/s": round(valu_insts / launch_s / 1e9, 1) if valu_insts else None,
+            "valu": {"wave_insts_per_launch": valu_insts, "Ginst/s": round(valu_ginst, 1) if valu_ginst else None,
                      "peak_Ginst/s": VALU_PEAK_GINST, "frac_of_valu_peak": round(valu_frac, 4) if valu_frac is not None else None,
+                     "salu_insts_per_launch": counters.get("salu_insts_per_launch"),
                      "lane_utilisation": counters.get("valu_lane_utilisation"),
                      # SQ_ACTIVE_INST_VALU (quad-cycles a SIMD spends executing VALU instructions) x 4 / SIMD cycles, kernels alone
                      # under rocprofv3 --pmc: the share of time the vector ALU port is taken.  frac_of_valu_peak prices every
                      # instruction at the 2 clocks of an fp32 FMA; conversions, integer, select and 3-operand instructions --
                      # most of a node step -- take 4 (tools/ubench/valu_asm.hip), which this counter sees
                      "busy_under_pmc": counters.get("valu_busy_under_pmc")},
-            "algorithmic_bytes_per_launch": round(alg_bytes[dominant] / max(1e-9, k_launches), 1),
+            "counters_commit": stamp.get("commit"), "counters_kernel_sha16": stamp.get("kernel_sources_sha16"), "benched_kernel_sha16": sha_now,
+            "counters_warning": counters_stale,
             "avg_launch_ms": round(k_ms / max(1e-9, k_launches), 5), "launches_per_step": round(k_launches, 2),
             "nodes_per_extend_ray": round(wc["nodesVisitedExtend"] / max(1, n_ext), 3),
             "tris_per_extend_ray": round(wc["trisTestedExtend"] / max(1, n_ext), 3),
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in ktimes.items()},
             "scene_record_bytes": scene_bytes, "cache_note": cache_note,
-            "note": "kernel durations are HIP-event pairs around every launch while batches overlap on two stream sets, as in the timed steps"}
+            "note": "kernel durations are HIP-event pairs around every launch while batches overlap on two stream sets, as in the timed steps; "
+                    "traffic / valu counters come from profiles/traffic.json (rocprofv3 --pmc passes of this command), stamped with the kernel sources they were taken on"}
 
 
 def cpu_baseline(spec, wl, flat, seconds):
@@ -391,6 +455,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        # every rank would measure its traversal mode on its own tiles: rank 0's choice is used by all (same balance everywhere)
+        r.begin_frame(cam, width, height, spp)
+        rdist.agree_traversal_mode(r, dist, rank, world)
     for _ in range(args.warmup):
         step()
     gather_ms.clear()

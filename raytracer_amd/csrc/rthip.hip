@@ -194,6 +194,10 @@ struct rthip_ctx
   uint32_t spillCap = 1;         // per-lane spill entries the uploaded BVH can need
   uint32_t tuneBlocks = 6;       // resident blocks per CU of k_trace's persistent grid (what 24 KB of LDS per block admits) ...
   uint32_t tuneBlocksLow = 3;    // ... and of its launches over slot lists (depth >= 1), see launchTrace (RTHIP_LIST_BLOCKS)
+  uint32_t tuneBlocksTail = 3;   // ... and of the list launches at depth >= 2 (RTHIP_TAIL_BLOCKS): short lists, latency-bound launches
+  uint32_t traceBlocksTail = 768;
+  uint32_t shadeTailBlocks = 128; // k_shade grid at depth >= 2, blocks per CU (RTHIP_SHADE_TAIL)
+  bool splitCalls = true;        // a call that fits one batch is still cut in two, one half per slot (RTHIP_NO_SPLIT=1: not)
   uint32_t traceBlocksMax = 2048; // numCUs * tuneBlocks: what the spill areas are sized for
   uint32_t overlapShadow = 1;    // run a depth's shadow and closest-hit launches on two streams (their tails overlap)
   uint32_t tuneSteal = kFetchShards; // spans a wave may pull chunks from: its own first, then the others' (1 = its own only).  Off in round 1 (+4 % on the soup
@@ -482,7 +486,7 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   {
     if (list)
     {
-      blocks = c->traceBlocks;
+      blocks = depth >= 2 ? c->traceBlocksTail : c->traceBlocks;
       a.chunkLen = 0;
     }
     else
@@ -658,15 +662,18 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, uint32_t tileB
     sa.listNext = last ? nullptr : listNext;
     {
       KernelTimer kt(c, 2);
+      // from depth 2 on the lists are short (hf10m: 4 % of the paths): a grid sized for the batch would be thousands of blocks
+      // that start only to find nothing to do
+      const uint32_t shadeGrid = d >= 2 ? std::min(shadeBlocks, (uint32_t)c->numCUs * c->shadeTailBlocks) : shadeBlocks;
       if (c->materialsOn)
       {
         if (d > 0)
-          hipLaunchKernelGGL((k_shade<true, true>), dim3(shadeBlocks), dim3(kBlock), 0, c->stream, sa);
+          hipLaunchKernelGGL((k_shade<true, true>), dim3(shadeGrid), dim3(kBlock), 0, c->stream, sa);
         else
           hipLaunchKernelGGL((k_shade<false, true>), dim3(shadeBlocks), dim3(kBlock), 0, c->stream, sa);
       }
       else if (d > 0)
-        hipLaunchKernelGGL((k_shade<true, false>), dim3(shadeBlocks), dim3(kBlock), 0, c->stream, sa);
+        hipLaunchKernelGGL((k_shade<true, false>), dim3(shadeGrid), dim3(kBlock), 0, c->stream, sa);
       else
         hipLaunchKernelGGL((k_shade<false, false>), dim3(shadeBlocks), dim3(kBlock), 0, c->stream, sa);
       HIPCHK(hipGetLastError());
@@ -713,21 +720,38 @@ BatchPlan planBatches(const rthip_ctx* c, uint32_t count, const FrameGeom& g, ui
   bp.samples = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(count, c->pathCap / perTile));
   bp.tiles = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g.numLocalTiles, c->pathCap / (perTile * bp.samples)));
   // a call that fits one batch but is big enough to fill the GPU twice over is cut in two, one half per slot
-  if (pipelined && bp.tiles == g.numLocalTiles && bp.samples == count && g.numLocalTiles >= 2 && perTile * g.numLocalTiles * count >= (1ull << 23))
+  if (pipelined && c->splitCalls && bp.tiles == g.numLocalTiles && bp.samples == count && g.numLocalTiles >= 2 && perTile * g.numLocalTiles * count >= (1ull << 23))
     bp.tiles = (g.numLocalTiles + 1) / 2;
   return bp;
 }
 
-// Decides between the low and the high refill thresholds of the traversal launches (k_trace: how many lanes must be idle
-// before a wave hands out new rays) by measuring: a sample of the frame -- a run of tiles from the middle of the local
-// tile list, the sample passes one call would bring, about 16M paths (as far as the path buffers allow) -- is traced three times on the main slot (once to warm
-// the caches, then with either setting) and timed with HIP events.  Nothing of it reaches the accumulator, the AOVs or the
-// counters.  Called by rthip_begin when the scene or the frame's shape has changed since the last measurement; costs a few
-// milliseconds and one synchronisation, then frames queue without waiting as before.
+// Decides how the traversal launches treat a wave's 64 rays -- low refill thresholds (incoherent rays), high thresholds
+// (coherent rays), packet traversal of camera rays and their hits' shadow rays, or packets for the camera rays only -- by
+// measuring, in the regime frames run in: TWO sample batches at a time, one on each slot (two runs of tiles from the middle of
+// the local tile list, the sample passes one call would bring, about 16M paths each, as far as the path buffers allow), so that
+// every candidate is timed with another batch beside it as in a pipelined frame (round 2 timed one batch alone, which is blind
+// to what overlap changes: the grid a setting leaves to the other batch, mode 3's win at few samples per pixel).  A frame that
+// is not pipelined (one slot) is measured on one slot.  Every candidate runs once untimed first (caches warm), nothing reaches
+// the accumulator, the AOVs or the counters.  Called by rthip_begin when the scene, its shading switches or the frame's shape
+// have changed since the last measurement: a few batches and one host synchronisation, then frames queue without waiting.
+uint64_t calibrationKey(const rthip_ctx* c)
+{
+  // FNV-1a over the fields themselves (round 2 XORed shifted fields, which overlap for large frames)
+  const uint32_t fields[] = {c->sceneEpoch, c->geom.width, c->geom.height, c->geom.numSamples, c->maxDepth, c->materialsOn ? 1u : 0u,
+                             (c->pointShadows && c->hostLights.numPoint) ? 1u : 0u, c->framePipelined ? 1u : 0u, c->geom.tileSize};
+  uint64_t h = 1469598103934665603ull;
+  for (uint32_t f : fields)
+    for (int b = 0; b < 4; ++b)
+    {
+      h ^= (f >> (8 * b)) & 0xffu;
+      h *= 1099511628211ull;
+    }
+  return h | 1ull; // never 0 (0 = nothing measured yet); the tile set is left out on purpose: a rank handed other tiles of the same frame keeps its choice
+}
+
 int calibrateRefill(rthip_ctx* c)
 {
-  const uint64_t key = ((uint64_t)c->sceneEpoch << 48) ^ ((uint64_t)c->geom.width << 32) ^ ((uint64_t)c->geom.height << 16) ^ ((uint64_t)c->geom.numSamples << 8) ^
-                       ((uint64_t)c->maxDepth << 2) ^ 1ull; // (not the tile set: a rank that is handed other tiles of the same frame keeps its choice)
+  const uint64_t key = calibrationKey(c);
   if (c->refillWanted >= 0)
   {
     c->refillMode = c->refillWanted;
@@ -743,27 +767,42 @@ int calibrateRefill(rthip_ctx* c)
   const uint32_t perTile = c->geom.tileSize * c->geom.tileSize;
   const uint32_t samples = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(c->geom.numSamples, 64u), c->pathCap / perTile));
   const uint64_t wantTiles = std::max<uint64_t>(1, (1ull << c->calibLog2) / ((uint64_t)perTile * samples));
+  const bool both = c->framePipelined && c->geom.numLocalTiles >= 2; // one sample batch per slot, side by side
   // never more slots than the path buffers were sized for (rthip_begin: the widest batch a render call of this frame makes)
-  const uint64_t slotCap = std::min<uint64_t>(std::min<uint64_t>(c->rayO.n, c->listA.n), std::min<uint64_t>(c->hit.n, c->pathCap));
-  const uint32_t tiles = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(wantTiles, c->geom.numLocalTiles), slotCap / ((uint64_t)perTile * samples));
+  uint64_t slotCap = std::min<uint64_t>(std::min<uint64_t>(c->rayO.n, c->listA.n), std::min<uint64_t>(c->hit.n, c->pathCap));
+  if (both)
+    slotCap = std::min<uint64_t>(slotCap, std::min<uint64_t>(std::min<uint64_t>(c->alt.rayO.n, c->alt.listA.n), c->alt.hit.n));
+  const uint32_t tiles = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(wantTiles, c->geom.numLocalTiles / (both ? 2u : 1u)), slotCap / ((uint64_t)perTile * samples));
   if (tiles == 0)
   {
     c->refillMode = 0;
     return 0;
   }
-  const uint32_t first = (c->geom.numLocalTiles - tiles) / 2;
+  const uint32_t span = both ? 2 * tiles : tiles;
+  const uint32_t first = (c->geom.numLocalTiles - span) / 2;
   const uint32_t keepBegin = c->lastBatchBegin, keepCount = c->lastBatchCount, keepSamp = c->lastSamp;
   const bool keepRendered = c->renderedAny, keepTiming = c->kernelTiming;
   c->kernelTiming = false;
   float ms[4] = {0, 0, 0, 0};
   int rc = 0;
-  // (mode 3, packets for camera rays only, is a manual setting: alone on the GPU -- as here -- it loses where it wins by 3 % in
-  // the pipelined frame (hf10m at 4 spp), so measuring it would only pick it where mode 2 is better anyway)
-  const int runs = packetsPossible(c) && c->fusedPrimary ? 4 : 3;
+  const bool packets = packetsPossible(c) && c->fusedPrimary && c->info.numNodes > 64;
+  const int numModes = packets ? 4 : 2;
   auto timedRun = [&](float* msOut) {
     rc = (int)hipEventRecord(c->evA, c->stream);
+    if (!rc && both)
+      rc = (int)hipStreamWaitEvent(c->alt.stream, c->evA, 0);
     if (!rc)
       rc = renderBatch(c, 0, samples, first, tiles, false, nullptr, true);
+    if (!rc && both)
+    {
+      swapSlot(c);
+      rc = renderBatch(c, 0, samples, first + tiles, tiles, false, nullptr, true);
+      if (!rc)
+        rc = (int)hipEventRecord(c->evDone, c->stream);
+      swapSlot(c);
+      if (!rc)
+        rc = (int)hipStreamWaitEvent(c->stream, c->alt.evDone, 0);
+    }
     if (!rc)
       rc = (int)hipEventRecord(c->evB, c->stream);
     if (!rc)
@@ -771,27 +810,24 @@ int calibrateRefill(rthip_ctx* c)
     if (!rc && msOut)
       rc = (int)hipEventElapsedTime(msOut, c->evA, c->evB);
   };
-  for (int run = 0; run < runs && !rc; ++run)
+  for (int mode = 0; mode < numModes && !rc; ++mode)
   {
-    c->refillMode = run == 0 ? 0 : run - 1;
-    timedRun(run > 0 ? &ms[run - 1] : nullptr);
-  }
-  if (!rc)
-  {
-    // anything but the low thresholds must win by more than the noise of the measurement
-    c->refillMode = 0;
-    float bestMs = 0.98f * ms[0];
-    for (int m = 1; m < runs - 1; ++m)
-      if (ms[m] < bestMs)
-        bestMs = ms[m], c->refillMode = m;
+    c->refillMode = mode;
+    if (mode == 0)
+      timedRun(nullptr); // warm the caches once
+    if (!rc)
+      timedRun(&ms[mode]);
   }
   c->kernelTiming = keepTiming;
   c->lastBatchBegin = keepBegin, c->lastBatchCount = keepCount, c->lastSamp = keepSamp, c->renderedAny = keepRendered;
+  c->refillMode = 0;
   if (rc)
-  {
-    c->refillMode = 0;
     return rc;
-  }
+  // anything but the low thresholds must win by more than the noise of the measurement
+  float bestMs = 0.98f * ms[0];
+  for (int m = 1; m < numModes; ++m)
+    if (ms[m] > 0.0f && ms[m] < bestMs)
+      bestMs = ms[m], c->refillMode = m;
   c->refillMs[0] = ms[0], c->refillMs[1] = ms[1], c->refillMs[2] = ms[2], c->refillMs[3] = ms[3];
   c->refillKey = key;
   return 0;
@@ -919,6 +955,16 @@ static int createContext(rthip_ctx* c, int device)
     if (v >= 1 && v <= 8)
       c->tuneBlocksLow = (uint32_t)v;
   }
+  if (const char* t = getenv("RTHIP_TAIL_BLOCKS"))
+  {
+    const int v = atoi(t);
+    if (v >= 1 && v <= 8)
+      c->tuneBlocksTail = (uint32_t)v;
+  }
+  if (const char* t = getenv("RTHIP_SHADE_TAIL"))
+    c->shadeTailBlocks = (uint32_t)std::max(1, std::min(128, atoi(t)));
+  if (const char* t = getenv("RTHIP_NO_SPLIT"))
+    c->splitCalls = atoi(t) == 0;
   if (const char* t = getenv("RTHIP_PATHCAP_LOG2")) // tuning experiments only
   {
     const int v = atoi(t);
@@ -946,6 +992,7 @@ static int createContext(rthip_ctx* c, int device)
   // list launches at 3 / 4 / 6 blocks per CU on one box: soup1m 3.28 / 3.38 / 3.47 ms, hf10m 165 / 167 / 169 ms, hf10m at 4 spp
   // 18.8 / 18.9 / 19.6 ms, cube 1.05 / 1.06 / 1.18 ms.  (A single small frame alone on the GPU prefers 6 by up to 8 %.)
   c->traceBlocks = std::min(c->traceBlocksMax, (uint32_t)c->numCUs * c->tuneBlocksLow);
+  c->traceBlocksTail = std::min(c->traceBlocksMax, (uint32_t)c->numCUs * c->tuneBlocksTail);
   // the static scratch of rthip_trace_rays_static: resolved once per device, with that device current
   if (device < kMaxDevices && !g_scratchPtr[device])
   {
@@ -1384,8 +1431,9 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
       return RTHIP_E_BOUNDS;
   }
   HIPCHK(hipSetDevice(c->device));
-  // No host synchronisation here: a frame is enqueued behind the previous one on the context's streams, so a caller that
-  // uses rthip_enqueue_passes keeps the GPU busy across frames (buffers only ever grow, and growing one synchronises).
+  // No host synchronisation here in the steady state: a frame is enqueued behind the previous one on the context's streams, so
+  // a caller that uses rthip_enqueue_passes keeps the GPU busy across frames.  Exceptions, all one-off: a buffer that has to grow,
+  // a changed tile table, and the traversal-mode measurement at the end (first frame of a scene / frame shape: calibrateRefill).
   // Everything is validated and sized into locals first; the context's frame state changes only once nothing can fail.
   const uint32_t tilesX = (f->width + ts - 1) / ts, tilesY = (f->height + ts - 1) / ts;
   FrameGeom g{};
@@ -1491,7 +1539,14 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
     c->altPending = true;
   c->renderedAny = false;
   c->haveFrame = true;
-  return calibrateRefill(c); // a no-op unless the scene or the frame's shape changed since the last measurement
+  // a no-op unless the scene, its shading switches or the frame's shape changed since the last measurement; when it does
+  // measure, this call renders a few sample batches and waits for them (the one host synchronisation rthip_begin can make)
+  if (int rcCal = calibrateRefill(c))
+  {
+    c->haveFrame = false; // the frame is not usable: the caller begins again
+    return rcCal;
+  }
+  return 0;
 }
 
 int rthip_set_refill_mode(rthip_ctx* c, int mode)

@@ -176,6 +176,17 @@ def init_native_comm(renderer, dist, rank, world_size):
     agreed(rc == 0, "rthip_comm_init: " + capi.error_string(rc))
 
 
+def agree_traversal_mode(renderer, dist, rank, world_size):
+    """Every rank measures its traversal mode on a sample of ITS tiles (rthip_begin -> calibrateRefill), so ranks could settle
+    on different modes: the frame's bits would not change, the balance would.  Rank 0's measured choice is broadcast and
+    fixed on every rank (rthip_set_refill_mode).  Call after the first begin_frame.  Returns the agreed mode."""
+    mode = [int(renderer.refill_mode()[0]) if rank == 0 else None]
+    if world_size > 1:
+        dist.broadcast_object_list(mode, src=0)
+    renderer.set_option("refillMode", mode[0])
+    return mode[0]
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Dynamic tile ownership (SURVEY.md 8d config 5): over-decomposed tiles handed out from one shared cursor, so a GPU whose
 # tiles were cheap takes more of them instead of idling through the others' tail.  A whole tile (all its samples) is

@@ -4,7 +4,7 @@
 # land in profiles/ under the given tag (and are mirrored to gpurun_out/profiles_<tag>/ so they come back from the box).
 #   usage: tools/profile_round.sh <tag>        (run through gpurun; every GPU step has its own time limit)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 mkdir -p gpurun_out profiles
 for WL in hf10m soup1m; do
@@ -15,8 +15,12 @@ for WL in hf10m soup1m; do
   bash tools/profile_pmc.sh $TAG $WL $STEPS > gpurun_out/${TAG}_${WL}_pmc.log 2>&1 || { echo "pmc $WL failed"; tail -5 gpurun_out/${TAG}_${WL}_pmc.log; exit 1; }
   D=gpurun_out/kt_${TAG}_${WL}
   KS=10; [ $WL = hf10m ] && KS=4
-  timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --workload $WL --steps $KS --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_${WL}_kt.log 2>&1 || { echo "kernel trace $WL failed"; tail -5 gpurun_out/${TAG}_${WL}_kt.log; exit 1; }
+  # --no-roofline: only frames that run like the timed ones (warm-up + timed steps, queued back to back on the two slots; the
+  # traversal mode is pinned above, so no calibration batches either) reach the CSV: its average launch durations are the ones
+  # bench.py's live avg_launch_ms measures with HIP events in its overlapped timing frames
+  timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --workload $WL --steps $KS --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/${TAG}_${WL}_kt.log 2>&1 || { echo "kernel trace $WL failed"; tail -5 gpurun_out/${TAG}_${WL}_kt.log; exit 1; }
   cp "$(find $D -name '*kernel_stats.csv' | head -1)" profiles/${TAG}_${WL}_kernel_stats.csv || exit 1
+  python3 tools/family_stats.py profiles/${TAG}_${WL}_kernel_stats.csv $((KS + 1)) > profiles/${TAG}_${WL}_family_stats.json || exit 1
   grep "^{\"metric\"" gpurun_out/${TAG}_${WL}_kt.log | tail -n 1 > profiles/${TAG}_${WL}_bench_under_rocprof.json
   rm -rf $D gpurun_out/pmc_${TAG}_${WL}
 done

@@ -126,8 +126,29 @@ def main():
                                  "passes of `bench.py --workload <name>` (tools/profile_pmc.sh): HBM bytes per launch = 2*FETCH_SIZE*1024 + "
                                  "WRITE_SIZE*1024 (gfx950 correction of MI355X_MICROARCH.md), VALU wave-instructions per launch, L2 hit rate, lane "
                                  "utilisation; bench.py divides by ITS OWN live launch durations"}}
+        families = dict(families)
+        families["_stamp"] = stamp()
         doc[workload] = families
         json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
+
+
+def stamp():
+    """what the counters belong to: the fingerprint of the kernel sources (bench.py compares it with the sources it runs on)
+    and, where a git checkout is at hand, the commit"""
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    st = {"kernel_sources_sha16": bench.kernel_sources_sha16(), "collected": time.strftime("%Y-%m-%d %H:%M:%S")}
+    commit = os.environ.get("RT_COMMIT")
+    if not commit:
+        try:
+            commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+        except Exception:
+            commit = None
+    st["commit"] = commit
+    return st
 
 
 NUM_SIMD, NUM_XCD = 256 * 4, 8
