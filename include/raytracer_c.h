@@ -59,7 +59,7 @@ int rt_generate(rt_renderer*);                                                 /
  * "referenceEdgeIndexing","maxLeafTriangles","sahBins","traversalCost","buildThreads","originBoundScale","materials" (1: a hit's albedo / emissive come
  * from its mesh's material instead of the constants of src/cpu/CPUScene.cpp:243-247), "pointShadows" (1: point lights cast shadow
  * rays as in src/metal/Compute.metal:238-254; needs <= 32 lights in all), "deviceBvh" (1: the triangle-level BVH is
- * built on the device, rthip_upload_scene_build, instead of by the host's binned-SAH builder),"countWork","kernelTiming","fusedPrimary","pipelining","overlapShadow",
+ * built on the device, rthip_upload_scene_build, as a Morton LBVH with SAH leaves instead of by the host's binned-SAH builder; 2: the same with PLOC clustering),"countWork","kernelTiming","fusedPrimary","pipelining","overlapShadow",
  * "refillMode" (-1 measured (default), 0 / 1 / 2 / 3 fixed: rthip_set_refill_mode)};
  * scene options must be set before rt_generate */
 int rt_set_option(rt_renderer*, const char* name, double value);

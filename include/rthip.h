@@ -104,6 +104,20 @@ int rthip_upload_scene(rthip_ctx* ctx, const rtflat_info* info, const rtflat_mod
 int rthip_upload_scene_build(rthip_ctx* ctx, rtflat_info* info, rtflat_model_node* modelNodes, const rtflat_tri* trisModelOrder,
                              uint32_t maxLeafTris, const rthip_dir_light* dirLights, uint32_t numDirLights,
                              const rthip_point_light* pointLights, uint32_t numPointLights, float* buildMsOut);
+/* how rthip_upload_scene_build forms the binary tree it then collapses: 0 (default) = Morton-order radix tree (LBVH; the code's
+ * bits are dealt to the axes longest-extent-first), 1 = PLOC, parallel locally-ordered clustering over the Morton order
+ * (nearest-neighbour merging by surface area; measured 4-7 % slower to trace than 0 on the benchmark scenes, kept as an
+ * experiment).  Either way a subtree ends in a leaf where the surface-area heuristic says so.  Hit results do not depend on it. */
+int rthip_set_build_quality(rthip_ctx* ctx, int quality);
+/* Moved vertices, same triangles: every record takes the new operands of its triangle (trisModelOrder: one rtflat_tri per
+ * triangle in pool order, as for rthip_upload_scene_build; triId / orderKey are kept) and the boxes of the triangle-level tree
+ * are recomputed bottom-up and quantised afresh; the model-level nodes take the boxes of modelNodes (same tree, numModelNodes
+ * entries: the reference's Model::transform boxes of the moved models, src/util/Model.cpp:3-26).  Topology and leaf contents
+ * stay, so the tree is as good as the motion is small.  The new triangles must stay within one scene diagonal of the box the
+ * scene was flattened for (rtflat_info.sceneLo/Hi: the padding of every box was sized for coordinates that far out); otherwise
+ * RTHIP_E_BOUNDS and the scene has to be uploaded again.  Waits for frames in flight, returns when done; msOut (may be NULL): device milliseconds.  The reference has
+ * no counterpart (its CPU path keeps no triangle-level tree). */
+int rthip_refit(rthip_ctx* ctx, const rtflat_model_node* modelNodes, const rtflat_tri* trisModelOrder, float* msOut);
 /* copies the scene's node / triangle records back from the device (either pointer may be NULL) */
 int rthip_download_scene(rthip_ctx* ctx, rtflat_node* nodesOut, uint32_t nodeCapacity, rtflat_tri* trisOut, uint32_t triCapacity);
 

@@ -115,6 +115,9 @@ def hip_lib():
         L.rthip_get_kernel_times.argtypes = [vp, fp, up]
         L.rthip_upload_materials.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64]
         L.rthip_set_point_shadows.argtypes = [vp, C.c_int]
+        L.rthip_set_build_quality.argtypes = [vp, C.c_int]
+        L.rthip_refit.argtypes = [vp, vp, vp, fp]
+        L.rthip_download_scene.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
         L.rthip_begin.argtypes = [vp, C.POINTER(Camera), C.POINTER(FrameDesc)]
         L.rthip_set_refill_mode.argtypes = [vp, C.c_int]
         L.rthip_get_refill_mode.argtypes = [vp, C.POINTER(C.c_int), fp]
@@ -451,6 +454,18 @@ class Renderer:
 
         texels = view(tx, 3 * nt.value, np.dtype("<f4")).reshape(-1, 3) if tx.value else np.zeros((0, 3), np.float32)
         return dict(_owner=self, shade=view(sh, n_tris, SHADE_DTYPE), materials=view(mt, nm.value, MATERIAL_DTYPE), texels=texels)
+
+    def refit(self, moved):
+        """rthip_refit: the scene takes the vertex positions of `moved` -- a renderer (any backend, "hip-offline" will do) holding
+        the SAME meshes, triangle for triangle, with moved vertices -- without rebuilding its triangle-level tree.  Returns the
+        device milliseconds."""
+        f = moved.flat()
+        order = np.argsort(f["tris"]["triId"], kind="stable")  # leaf order -> pool order
+        tris = np.ascontiguousarray(f["tris"][order])
+        nodes = np.ascontiguousarray(f["model_nodes"])
+        ms = C.c_float(0)
+        _check(hip_lib().rthip_refit(self.context, nodes.ctypes.data, tris.ctypes.data, C.byref(ms)), "rthip_refit")
+        return float(ms.value)
 
     def refill_mode(self):
         """(traversal mode in use: 0 low / 1 high refill thresholds / 2 packet traversal of camera and first shadow rays / 3 of camera

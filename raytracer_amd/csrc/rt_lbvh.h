@@ -3,15 +3,25 @@
 // flattener's binned-SAH builder (src/scene/BvhFlattener.cpp) stays as the quality baseline, this is the fast path:
 //
 //   k_lbvh_prims     padded triangle boxes (same rule as the flattener: padAbs x sliver factor) + 63-bit Morton codes of
-//                    their centres
+//                    their centres; the code's bits are dealt to the axes longest-extent-first (a terrain two units wide and a
+//                    third of a unit high gets its first height bit only after x and z have been halved twice or three times)
 //   rocprim          radix sort of (code, triangle) pairs
-//   k_lbvh_topology  binary radix tree over the sorted codes (Karras 2012), one thread per inner node
-//   k_lbvh_refit     boxes bottom-up, one launch per tree level (a node is finished once both children were finished by an
-//                    EARLIER launch: kernel boundaries order the box writes, no in-kernel hand-off between CUs)
+//   binary tree, one of
+//    quality 0 (LBVH):  k_lbvh_topology  binary radix tree over the sorted codes (Karras 2012), one thread per inner node
+//                       k_lbvh_refit     boxes bottom-up, one launch per tree level (a node is finished once both children were
+//                                        finished by an EARLIER launch: kernel boundaries order the box writes)
+//    quality 1 (PLOC, Meister & Bittner 2018: parallel locally-ordered clustering; round 3, the default):
+//                       k_ploc_nearest   every cluster of the Morton-ordered cluster array finds, among its `radius` neighbours
+//                                        on either side, the one whose union with it has the smallest surface area
+//                       k_ploc_merge     mutual nearest neighbours become one inner node (box = the union: no refit pass)
+//                       rocprim scan + k_ploc_compact   the surviving clusters close ranks, order kept
+//                                        ... repeated until one cluster is left (about 35 rounds for 10 M triangles)
 //   k_lbvh_emit      collapse to 4-wide nodes level by level from the root (the child with the largest box is opened until
 //                    the node has four children or only leaves), child boxes quantised outward onto the node's 8-bit grid:
-//                    the same rtflat_node records the host builder writes, in breadth-first order
-//   k_lbvh_gather    triangle records into leaf (= sorted) order
+//                    the same rtflat_node records the host builder writes, in breadth-first order; triangle ranges are dealt
+//                    top-down (a node's triangles are a contiguous run of the final record order) and every leaf writes which
+//                    triangles it holds
+//   k_lbvh_gather    triangle records into that (leaf) order
 //
 // Hit results do not depend on the tree (closest hits are an arg-min with the orderKey tie rule, any-hits a disjunction), so
 // a scene renders bit-identically through either builder.
@@ -25,31 +35,22 @@ struct LbvhBox
   float lo[3], hi[3];
 };
 
-struct LbvhNode // binary radix-tree node
+struct LbvhNode // binary tree node (radix tree or PLOC)
 {
   uint32_t left, right; // bit 31 set: a leaf = sorted triangle index in the low bits
-  uint32_t first, last; // range of sorted triangles it covers (inclusive)
+  uint32_t count;       // triangles below it
+  uint32_t pad;
 };
 
-__device__ __forceinline__ uint64_t spread21(uint32_t v)
+// where each bit of the three 21-bit quantised coordinates goes in the 63-bit code (bit 20 of an axis first)
+struct MortonLayout
 {
-  uint64_t x = v & 0x1fffffu;
-  x = (x | x << 32) & 0x1f00000000ffffull;
-  x = (x | x << 16) & 0x1f0000ff0000ffull;
-  x = (x | x << 8) & 0x100f00f00f00f00full;
-  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
-  x = (x | x << 2) & 0x1249249249249249ull;
-  return x;
-}
+  uint8_t pos[3][21];
+};
 
-// tris: the model's records in model order; boxes/codes/ids: n entries
-__global__ __launch_bounds__(kBlock) void k_lbvh_prims(const rtflat_tri* tris, uint32_t n, float padAbs, float3 sceneLo, float3 sceneInvExt, LbvhBox* boxes,
-                                                       uint64_t* codes, uint32_t* ids)
+// the padded box of a triangle record: same rule as the flattener (padAbs x sliver factor, see BvhFlattener.cpp)
+__device__ __forceinline__ LbvhBox lbvhTriangleBox(const rtflat_tri& t, float padAbs)
 {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n)
-    return;
-  const rtflat_tri& t = tris[i];
   const vec3 p0{t.p0[0], t.p0[1], t.p0[2]}, e0{t.e0[0], t.e0[1], t.e0[2]}, e1{t.e1[0], t.e1[1], t.e1[2]};
   const vec3 p1 = p0 + e0, p2 = p0 + e1;
   const vec3 nrm = rt::cross(e0, e1);
@@ -77,12 +78,31 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_prims(const rtflat_tri* tris, u
   LbvhBox b;
   b.lo[0] = fminf(p0.x, fminf(p1.x, p2.x)) - pad, b.lo[1] = fminf(p0.y, fminf(p1.y, p2.y)) - pad, b.lo[2] = fminf(p0.z, fminf(p1.z, p2.z)) - pad;
   b.hi[0] = fmaxf(p0.x, fmaxf(p1.x, p2.x)) + pad, b.hi[1] = fmaxf(p0.y, fmaxf(p1.y, p2.y)) + pad, b.hi[2] = fmaxf(p0.z, fmaxf(p1.z, p2.z)) + pad;
+  return b;
+}
+
+// tris: the model's records in model order; boxes/codes/ids: n entries
+__global__ __launch_bounds__(kBlock) void k_lbvh_prims(const rtflat_tri* tris, uint32_t n, float padAbs, float3 sceneLo, float3 sceneInvExt, MortonLayout layout,
+                                                       LbvhBox* boxes, uint64_t* codes, uint32_t* ids)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n)
+    return;
+  const LbvhBox b = lbvhTriangleBox(tris[i], padAbs);
   boxes[i] = b;
   const float cx = (0.5f * (b.lo[0] + b.hi[0]) - sceneLo.x) * sceneInvExt.x, cy = (0.5f * (b.lo[1] + b.hi[1]) - sceneLo.y) * sceneInvExt.y,
               cz = (0.5f * (b.lo[2] + b.hi[2]) - sceneLo.z) * sceneInvExt.z;
   const uint32_t qx = (uint32_t)(fminf(fmaxf(cx, 0.0f), 1.0f) * 2097151.0f), qy = (uint32_t)(fminf(fmaxf(cy, 0.0f), 1.0f) * 2097151.0f),
                  qz = (uint32_t)(fminf(fmaxf(cz, 0.0f), 1.0f) * 2097151.0f);
-  codes[i] = (spread21(qx) << 2) | (spread21(qy) << 1) | spread21(qz);
+  uint64_t code = 0;
+#pragma unroll
+  for (int k = 0; k < 21; ++k)
+  {
+    code |= (uint64_t)((qx >> (20 - k)) & 1u) << layout.pos[0][k];
+    code |= (uint64_t)((qy >> (20 - k)) & 1u) << layout.pos[1][k];
+    code |= (uint64_t)((qz >> (20 - k)) & 1u) << layout.pos[2][k];
+  }
+  codes[i] = code;
   ids[i] = i;
 }
 
@@ -127,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_topology(const uint64_t* codes,
   LbvhNode nd;
   nd.left = (first == gamma) ? (0x80000000u | (uint32_t)gamma) : (uint32_t)gamma;
   nd.right = (last == gamma + 1) ? (0x80000000u | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
-  nd.first = (uint32_t)first, nd.last = (uint32_t)last;
+  nd.count = (uint32_t)(last - first + 1), nd.pad = 0;
   nodes[i] = nd;
 }
 
@@ -165,6 +185,103 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_refit(const LbvhNode* nodes, ui
   done[i] = (uint8_t)pass;
 }
 
+// ------------------------------------------------------------------------------------------------ PLOC
+__device__ __forceinline__ float lbvhHalfArea(const LbvhBox& b)
+{
+  const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+constexpr uint32_t kPlocMaxRadius = 32;
+
+// nearest[i] = the cluster within `radius` positions of i whose union with cluster i has the smallest surface area (the
+// lower position on a tie).  A block stages its clusters' boxes and the radius on either side in LDS.
+__global__ __launch_bounds__(kBlock) void k_ploc_nearest(const LbvhBox* boxes, uint32_t count, uint32_t radius, uint32_t* nearest)
+{
+  __shared__ LbvhBox sBox[kBlock + 2 * kPlocMaxRadius];
+  const int base = (int)(blockIdx.x * kBlock) - (int)radius;
+  for (uint32_t k = threadIdx.x; k < kBlock + 2 * radius; k += kBlock)
+  {
+    const int src = base + (int)k;
+    if (src >= 0 && src < (int)count)
+      sBox[k] = boxes[src];
+  }
+  __syncthreads();
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count)
+    return;
+  const LbvhBox mine = sBox[threadIdx.x + radius];
+  float best = FLT_MAX;
+  uint32_t bestJ = i; // (count >= 2 whenever this runs, so a neighbour exists)
+  const int lo = max(0, (int)i - (int)radius), hi = min((int)count - 1, (int)i + (int)radius);
+  for (int j = lo; j <= hi; ++j)
+  {
+    if (j == (int)i)
+      continue;
+    const float a = lbvhHalfArea(lbvhUnion(mine, sBox[j - base]));
+    if (a < best)
+      best = a, bestJ = (uint32_t)j;
+  }
+  nearest[i] = bestJ;
+}
+
+// mutual nearest neighbours (i, j), i < j, merge into a new inner node that takes i's place; j's place is flagged empty.
+// Everything else stays.  In place: a pair is handled by the thread of its lower position, which alone reads and writes both.
+__global__ __launch_bounds__(kBlock) void k_ploc_merge(uint32_t* refs, LbvhBox* boxes, uint32_t count, const uint32_t* nearest, uint32_t* nodeCounter, LbvhNode* nodes,
+                                                       LbvhBox* innerBoxes, uint32_t* flags)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count)
+    return;
+  const uint32_t j = nearest[i];
+  uint32_t keep = 1;
+  if (j != i && nearest[j] == i)
+  {
+    if (i < j)
+    {
+      const uint32_t ri = refs[i], rj = refs[j];
+      const LbvhBox u = lbvhUnion(boxes[i], boxes[j]);
+      const uint32_t idx = atomicAdd(nodeCounter, 1u);
+      LbvhNode nd;
+      nd.left = ri, nd.right = rj;
+      nd.count = ((ri & 0x80000000u) ? 1u : nodes[ri].count) + ((rj & 0x80000000u) ? 1u : nodes[rj].count);
+      nd.pad = 0;
+      nodes[idx] = nd;
+      innerBoxes[idx] = u;
+      refs[i] = idx;
+      boxes[i] = u;
+    }
+    else
+      keep = 0;
+  }
+  flags[i] = keep;
+}
+
+// the surviving clusters close ranks (order kept); the last thread publishes the new count
+__global__ __launch_bounds__(kBlock) void k_ploc_compact(const uint32_t* refs, const LbvhBox* boxes, const uint32_t* flags, const uint32_t* offsets, uint32_t count,
+                                                         uint32_t* refsOut, LbvhBox* boxesOut, uint32_t* countOut)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count)
+    return;
+  if (flags[i])
+  {
+    refsOut[offsets[i]] = refs[i];
+    boxesOut[offsets[i]] = boxes[i];
+  }
+  if (i == count - 1)
+    *countOut = offsets[i] + flags[i];
+}
+
+// the initial cluster array: one cluster per triangle, in Morton order
+__global__ __launch_bounds__(kBlock) void k_ploc_init(const LbvhBox* primBoxes, const uint32_t* ids, uint32_t n, uint32_t* refs, LbvhBox* boxes)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n)
+    return;
+  refs[i] = 0x80000000u | i;
+  boxes[i] = primBoxes[ids[i]];
+}
+
 struct LbvhEmitArgs
 {
   const LbvhNode* nodes;
@@ -175,9 +292,11 @@ struct LbvhEmitArgs
   uint32_t outCapacity;   // entries of `out`
   uint32_t* nodeCounter;  // next free entry of `out`
   uint32_t recordBase;    // first rtflat_tri record of this model (leaf references are absolute)
-  uint32_t maxLeaf;       // a subtree of at most this many triangles becomes a leaf
-  const uint2* frontierIn;  // (binary inner node, its entry in `out`)
-  uint2* frontierOut;
+  uint32_t maxLeaf;       // a subtree of at most this many triangles may become a leaf ...
+  float traversalCost;    // ... and does when the surface-area heuristic prefers it: cost of visiting a node relative to a triangle test
+  uint32_t* order;        // [first + k] = the (model-order) triangle that ends up as record recordBase + first + k
+  const uint4* frontierIn;  // (binary inner node, its entry in `out`, first record of its triangle range, -)
+  uint4* frontierOut;
   const uint32_t* countIn;
   uint32_t* countOut;
   uint32_t* overflow;
@@ -187,7 +306,7 @@ struct LbvhCandidate
 {
   uint32_t ref; // binary child reference (bit 31: single sorted triangle)
   LbvhBox box;
-  uint32_t first, count;
+  uint32_t count;
 };
 
 __device__ __forceinline__ LbvhCandidate lbvhCandidate(const LbvhEmitArgs& a, uint32_t ref)
@@ -198,15 +317,31 @@ __device__ __forceinline__ LbvhCandidate lbvhCandidate(const LbvhEmitArgs& a, ui
   {
     const uint32_t k = ref & 0x7fffffffu;
     c.box = a.primBoxes[a.ids[k]];
-    c.first = k, c.count = 1;
+    c.count = 1;
   }
   else
   {
     c.box = a.innerBoxes[ref];
-    const LbvhNode nd = a.nodes[ref];
-    c.first = nd.first, c.count = nd.last - nd.first + 1;
+    c.count = a.nodes[ref].count;
   }
   return c;
+}
+
+// Does this subtree end here?  A single triangle does; a subtree of at most maxLeaf triangles does when testing all of them on
+// every visit is no dearer, by the surface-area heuristic, than one more node visit plus its two halves as leaves -- the host
+// builder's rule (BvhFlattener.cpp: n * A <= traversalCost * A + sum(n_child * A_child)).  Two triangles of one quad stay
+// together (their boxes nearly coincide); four scattered soup triangles do not (round 3: taking every subtree of <= 4 triangles
+// as a leaf made the 1 M soup test 22 triangles per ray against the host tree's 5.6).
+__device__ __forceinline__ bool lbvhEndsHere(const LbvhEmitArgs& a, const LbvhCandidate& c)
+{
+  if (c.ref & 0x80000000u)
+    return true;
+  if (c.count > a.maxLeaf)
+    return false;
+  const LbvhNode nd = a.nodes[c.ref];
+  const LbvhCandidate l = lbvhCandidate(a, nd.left), r = lbvhCandidate(a, nd.right);
+  const float area = lbvhHalfArea(c.box);
+  return (float)c.count * area <= a.traversalCost * area + ((float)l.count * lbvhHalfArea(l.box) + (float)r.count * lbvhHalfArea(r.box));
 }
 
 // quantises the child boxes outward onto the node's 8-bit grid (the device twin of quantiseNode in BvhFlattener.cpp)
@@ -266,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_emit(LbvhEmitArgs a)
   const uint32_t total = *a.countIn;
   for (uint32_t item = blockIdx.x * kBlock + threadIdx.x; item < total; item += gridDim.x * kBlock)
   {
-    const uint2 fr = a.frontierIn[item];
+    const uint4 fr = a.frontierIn[item];
     const LbvhNode nd = a.nodes[fr.x];
     LbvhCandidate cand[4];
     uint32_t n = 2;
@@ -277,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_emit(LbvhEmitArgs a)
       int pick = -1;
       float bestArea = -1.0f;
       for (uint32_t k = 0; k < n; ++k)
-        if (!(cand[k].ref & 0x80000000u) && cand[k].count > a.maxLeaf)
+        if (!lbvhEndsHere(a, cand[k]))
         {
           const float dx = cand[k].box.hi[0] - cand[k].box.lo[0], dy = cand[k].box.hi[1] - cand[k].box.lo[1], dz = cand[k].box.hi[2] - cand[k].box.lo[2];
           const float area = dx * dy + dy * dz + dz * dx;
@@ -297,21 +432,45 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_emit(LbvhEmitArgs a)
       ++n;
     }
     uint32_t childRef[4] = {RTFLAT_INVALID, RTFLAT_INVALID, RTFLAT_INVALID, RTFLAT_INVALID};
-    for (uint32_t k = 0; k < n; ++k)
+    // the node's triangles are the run [fr.z, fr.z + count) of the final record order, dealt to the children in their order
+    uint32_t first = fr.z;
+    for (uint32_t k = 0; k < n; first += cand[k].count, ++k)
     {
-      if ((cand[k].ref & 0x80000000u) || cand[k].count <= a.maxLeaf)
-        childRef[k] = rtflat_make_leaf(a.recordBase + cand[k].first, cand[k].count);
+      if (lbvhEndsHere(a, cand[k]))
+      {
+        childRef[k] = rtflat_make_leaf(a.recordBase + first, cand[k].count);
+        // which triangles: the leaves of the (at most maxLeaf-triangle) subtree, left to right
+        uint32_t stack[RTFLAT_MAX_LEAF_TRIS];
+        uint32_t sp = 0, w = first, cur = cand[k].ref;
+        for (;;)
+        {
+          if (cur & 0x80000000u)
+          {
+            a.order[w++] = a.ids[cur & 0x7fffffffu];
+            if (sp == 0)
+              break;
+            cur = stack[--sp];
+          }
+          else
+          {
+            const LbvhNode sub = a.nodes[cur];
+            if (sp < RTFLAT_MAX_LEAF_TRIS)
+              stack[sp++] = sub.right;
+            cur = sub.left;
+          }
+        }
+      }
       else
       {
         const uint32_t idx = atomicAdd(a.nodeCounter, 1u);
         if (idx >= a.outCapacity)
         {
           atomicExch(a.overflow, 1u);
-          childRef[k] = rtflat_make_leaf(a.recordBase + cand[k].first, 1); // keeps the arrays well-formed; the build is rejected
+          childRef[k] = rtflat_make_leaf(a.recordBase + first, 1); // keeps the arrays well-formed; the build is rejected
           continue;
         }
         childRef[k] = idx;
-        a.frontierOut[atomicAdd(a.countOut, 1u)] = make_uint2(cand[k].ref, idx);
+        a.frontierOut[atomicAdd(a.countOut, 1u)] = make_uint4(cand[k].ref, idx, first, 0u);
       }
     }
     rtflat_node node;
@@ -320,7 +479,7 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_emit(LbvhEmitArgs a)
   }
 }
 
-// triangle records into leaf (= sorted) order
+// triangle records into leaf order (order[i] = the model-order triangle that becomes record i)
 __global__ __launch_bounds__(kBlock) void k_lbvh_gather(const rtflat_tri* in, const uint32_t* ids, uint32_t n, rtflat_tri* out)
 {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -329,5 +488,82 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_gather(const rtflat_tri* in, co
   const float4* src = reinterpret_cast<const float4*>(in + ids[i]);
   float4* dst = reinterpret_cast<float4*>(out + i);
   dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
+}
+
+// ------------------------------------------------------------------------------------------------ refit (rthip_refit)
+// new geometry into the records of an existing tree: record r keeps its place, its triId and its orderKey and takes the
+// operands of triangle triId from the caller's model-order array; triangles that leave the box the scene was flattened for
+// raise `outside` (the padding of every box was sized for that box)
+__global__ __launch_bounds__(kBlock) void k_refit_tris(rtflat_tri* tris, const rtflat_tri* modelOrder, uint32_t n, float padAbs, float3 lo, float3 hi, uint32_t* outside)
+{
+  const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= n)
+    return;
+  rtflat_tri t = tris[r];
+  const rtflat_tri src = modelOrder[t.triId];
+  for (int k = 0; k < 3; ++k)
+    t.p0[k] = src.p0[k], t.e0[k] = src.e0[k], t.e1[k] = src.e1[k], t.n[k] = src.n[k];
+  tris[r] = t;
+  const LbvhBox b = lbvhTriangleBox(t, padAbs);
+  if (!(b.lo[0] >= lo.x && b.lo[1] >= lo.y && b.lo[2] >= lo.z && b.hi[0] <= hi.x && b.hi[1] <= hi.y && b.hi[2] <= hi.z))
+    atomicOr(outside, 1u);
+}
+
+// One level of the bottom-up refit of the 4-wide tree: a node whose inner children all got their boxes in EARLIER passes
+// recomputes its children's boxes (leaf children from their triangles, with the flattener's padding; inner children from
+// nodeBoxes) and quantises them afresh onto a grid of its own.  Topology, child order and leaf contents stay.
+__global__ __launch_bounds__(kBlock) void k_refit_nodes(rtflat_node* nodes, uint32_t numNodes, const rtflat_tri* tris, float padAbs, LbvhBox* nodeBoxes, uint8_t* done,
+                                                        uint32_t pass)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= numNodes || done[i])
+    return;
+  rtflat_node node = nodes[i];
+  const uint32_t n = node.numChildren;
+  LbvhCandidate cand[4];
+  uint32_t childRef[4];
+  for (uint32_t k = 0; k < 4; ++k)
+    childRef[k] = node.child[k];
+  for (uint32_t k = 0; k < n && k < 4; ++k)
+  {
+    const uint32_t ref = node.child[k];
+    cand[k].ref = ref, cand[k].count = 0;
+    if (rtflat_is_leaf(ref))
+    {
+      const uint32_t first = rtflat_leaf_first(ref), count = rtflat_leaf_count(ref);
+      LbvhBox b = lbvhTriangleBox(tris[first], padAbs);
+      for (uint32_t t = 1; t < count; ++t)
+        b = lbvhUnion(b, lbvhTriangleBox(tris[first + t], padAbs));
+      cand[k].box = b;
+    }
+    else
+    {
+      if (ref >= numNodes || !(done[ref] && done[ref] < pass))
+        return; // not yet: a later pass
+      cand[k].box = nodeBoxes[ref];
+    }
+  }
+  if (n == 0)
+  {
+    done[i] = (uint8_t)pass; // the placeholder node of a scene whose models are all single leaves
+    return;
+  }
+  LbvhBox all = cand[0].box;
+  for (uint32_t k = 1; k < n; ++k)
+    all = lbvhUnion(all, cand[k].box);
+  lbvhQuantise(cand, n, childRef, node);
+  nodes[i] = node;
+  nodeBoxes[i] = all;
+  done[i] = (uint8_t)pass;
+}
+
+// the model-level boxes are the reference's own (Model::transform's AABB, tested with its exact arithmetic): the caller brings them
+__global__ void k_refit_model_boxes(rtflat_model_node* dst, const rtflat_model_node* src, uint32_t n)
+{
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n)
+    return;
+  for (int a = 0; a < 3; ++a)
+    dst[k].lo[a] = src[k].lo[a], dst[k].hi[a] = src[k].hi[a];
 }
 } // namespace rtk

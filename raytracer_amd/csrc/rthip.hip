@@ -197,6 +197,9 @@ struct rthip_ctx
   uint32_t tuneBlocksTail = 3;   // ... and of the list launches at depth >= 2 (RTHIP_TAIL_BLOCKS): short lists, latency-bound launches
   uint32_t traceBlocksTail = 768;
   uint32_t shadeTailBlocks = 128; // k_shade grid at depth >= 2, blocks per CU (RTHIP_SHADE_TAIL)
+  int buildQuality = 0;          // device BVH build: 0 = Morton LBVH (default), 1 = PLOC over the Morton order (rthip_set_build_quality, RTHIP_BUILD_QUALITY)
+  float buildTraversalCost = 1.0f; // SAH cost of a node visit relative to a triangle test in the device build's leaf rule (RTHIP_BUILD_TCOST)
+  uint32_t plocRadius = 16;      // neighbours searched on either side (RTHIP_PLOC_RADIUS)
   bool splitCalls = true;        // a call that fits one batch is still cut in two, one half per slot (RTHIP_NO_SPLIT=1: not)
   uint32_t traceBlocksMax = 2048; // numCUs * tuneBlocks: what the spill areas are sized for
   uint32_t overlapShadow = 1;    // run a depth's shadow and closest-hit launches on two streams (their tails overlap)
@@ -963,6 +966,12 @@ static int createContext(rthip_ctx* c, int device)
   }
   if (const char* t = getenv("RTHIP_SHADE_TAIL"))
     c->shadeTailBlocks = (uint32_t)std::max(1, std::min(128, atoi(t)));
+  if (const char* t = getenv("RTHIP_BUILD_QUALITY"))
+    c->buildQuality = std::max(0, std::min(1, atoi(t)));
+  if (const char* t = getenv("RTHIP_BUILD_TCOST"))
+    c->buildTraversalCost = (float)std::max(0.0, atof(t));
+  if (const char* t = getenv("RTHIP_PLOC_RADIUS"))
+    c->plocRadius = (uint32_t)std::max(1, std::min((int)kPlocMaxRadius, atoi(t)));
   if (const char* t = getenv("RTHIP_NO_SPLIT"))
     c->splitCalls = atoi(t) == 0;
   if (const char* t = getenv("RTHIP_PATHCAP_LOG2")) // tuning experiments only
@@ -1181,22 +1190,34 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
   c->materialsOn = false;
   int rc;
   const uint32_t nodeCap = std::max(1u, numTris);
+  const bool ploc = c->buildQuality >= 1;
+  const uint32_t radius = std::max(1u, std::min(c->plocRadius, kPlocMaxRadius));
   DevBuf<rtflat_tri> trisIn;
-  DevBuf<LbvhBox> primBoxes, innerBoxes;
+  DevBuf<LbvhBox> primBoxes, innerBoxes, clusterBoxA, clusterBoxB;
   DevBuf<uint64_t> codes, codesSorted;
-  DevBuf<uint32_t> ids, idsSorted, small; // small: [nodeCounter | overflow | level counts (kLevels + 1)]
+  DevBuf<uint32_t> ids, idsSorted, order, small; // small: [nodeCounter | overflow | level counts (kLevels + 2) | binary node counter | cluster count]
+  DevBuf<uint32_t> clusterRefA, clusterRefB, nearest, flags, offsets;
   DevBuf<LbvhNode> binary;
-  DevBuf<uint8_t> done, sortTemp;
-  DevBuf<uint2> frontier;
+  DevBuf<uint8_t> done, sortTemp, scanTemp;
+  DevBuf<uint4> frontier;
   constexpr uint32_t kLevels = (kMaxStack - 2) / 3; // deepest chain of 4-wide nodes the traversal stack can take
+  constexpr uint32_t kSmallBinary = 2 + kLevels + 2, kSmallClusters = kSmallBinary + 1, kSmallWords = kSmallClusters + 1;
   if ((rc = c->modelNodes.ensure(info->numModelNodes)) || (rc = c->nodes.ensure(nodeCap)) || (rc = c->tris.ensure(numTris)) || (rc = c->lights.ensure(1)) ||
       (rc = trisIn.ensure(numTris)) || (rc = primBoxes.ensure(largest)) || (rc = innerBoxes.ensure(largest)) || (rc = codes.ensure(largest)) ||
       (rc = codesSorted.ensure(largest)) || (rc = ids.ensure(largest)) || (rc = idsSorted.ensure(largest)) || (rc = binary.ensure(largest)) ||
-      (rc = done.ensure(largest)) || (rc = frontier.ensure(2 * (size_t)largest)) || (rc = small.ensure(2 + kLevels + 2)))
+      (rc = order.ensure(largest)) || (rc = frontier.ensure(2 * (size_t)largest)) || (rc = small.ensure(kSmallWords)))
     return rc;
-  // temporary storage of the radix sort: rocPRIM picks its algorithm by size, so the requirement is asked for every model
-  // size that will be sorted and the largest answer is allocated (not assumed monotone in n)
-  size_t sortBytes = 0;
+  if (ploc)
+  {
+    if ((rc = clusterBoxA.ensure(largest)) || (rc = clusterBoxB.ensure(largest)) || (rc = clusterRefA.ensure(largest)) || (rc = clusterRefB.ensure(largest)) ||
+        (rc = nearest.ensure(largest)) || (rc = flags.ensure(largest)) || (rc = offsets.ensure(largest)))
+      return rc;
+  }
+  else if ((rc = done.ensure(largest)))
+    return rc;
+  // temporary storage of the radix sort (and of PLOC's prefix sum): rocPRIM picks its algorithm by size, so the requirement is
+  // asked for every model size that will be processed and the largest answer is allocated (not assumed monotone in n)
+  size_t sortBytes = 0, scanBytes = 0;
   for (uint32_t k = 0; k < info->numModelNodes; ++k)
   {
     const uint32_t n = modelNodes[k].triCount;
@@ -1206,8 +1227,21 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
     if (rocprim::radix_sort_pairs(nullptr, need, codes.p, codesSorted.p, ids.p, idsSorted.p, n, 0, 64, c->stream) != hipSuccess)
       return RTHIP_E_ARG;
     sortBytes = std::max(sortBytes, need);
+    if (ploc)
+    {
+      // (the scan runs on shrinking cluster arrays; powers of two down from n cover the size classes rocPRIM distinguishes)
+      for (uint32_t m = n; m >= 1; m = (m > 1 ? m / 2 : 0))
+      {
+        need = 0;
+        if (rocprim::exclusive_scan(nullptr, need, flags.p, offsets.p, 0u, m, rocprim::plus<uint32_t>(), c->stream) != hipSuccess)
+          return RTHIP_E_ARG;
+        scanBytes = std::max(scanBytes, need);
+        if (m == 1)
+          break;
+      }
+    }
   }
-  if ((rc = sortTemp.ensure(sortBytes)))
+  if ((rc = sortTemp.ensure(sortBytes)) || (rc = scanTemp.ensure(2 * scanBytes + 256)))
     return rc;
   HIPCHK(hipMemcpy(trisIn.p, trisModelOrder, sizeof(rtflat_tri) * numTris, hipMemcpyHostToDevice));
   HIPCHK(hipEventRecord(c->evA, c->stream));
@@ -1215,6 +1249,24 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
   const float3 sceneLo = make_float3(info->sceneLo[0], info->sceneLo[1], info->sceneLo[2]);
   auto inv = [](float e) { return e > 0.0f ? 1.0f / e : 0.0f; };
   const float3 sceneInvExt = make_float3(inv(info->sceneHi[0] - info->sceneLo[0]), inv(info->sceneHi[1] - info->sceneLo[1]), inv(info->sceneHi[2] - info->sceneLo[2]));
+  // Morton bit layout: the code's 63 bits, most significant first, go to whichever axis is longest at that point (its extent is
+  // then halved), each axis taking at most 21.  A cube-shaped scene gets the usual x,y,z interleave; a flat one spends its leading
+  // bits where the triangles actually spread.
+  MortonLayout layout;
+  {
+    double ext[3] = {std::max(0.0, (double)info->sceneHi[0] - info->sceneLo[0]), std::max(0.0, (double)info->sceneHi[1] - info->sceneLo[1]),
+                     std::max(0.0, (double)info->sceneHi[2] - info->sceneLo[2])};
+    uint32_t taken[3] = {0, 0, 0};
+    for (int bit = 62; bit >= 0; --bit)
+    {
+      int pick = -1;
+      for (int a = 0; a < 3; ++a)
+        if (taken[a] < 21 && (pick < 0 || ext[a] > ext[pick]))
+          pick = a;
+      layout.pos[pick][taken[pick]++] = (uint8_t)bit;
+      ext[pick] *= 0.5;
+    }
+  }
   for (uint32_t k = 0; k < info->numModelNodes; ++k)
   {
     rtflat_model_node& mn = modelNodes[k];
@@ -1229,30 +1281,68 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
       continue;
     }
     const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
-    hipLaunchKernelGGL(k_lbvh_prims, grid, block, 0, c->stream, trisIn.p + base, n, info->padAbs, sceneLo, sceneInvExt, primBoxes.p, codes.p, ids.p);
+    hipLaunchKernelGGL(k_lbvh_prims, grid, block, 0, c->stream, trisIn.p + base, n, info->padAbs, sceneLo, sceneInvExt, layout, primBoxes.p, codes.p, ids.p);
     HIPCHK(hipGetLastError());
     size_t sortBytesNow = sortBytes; // (rocPRIM takes the size by reference)
     if (rocprim::radix_sort_pairs(sortTemp.p, sortBytesNow, codes.p, codesSorted.p, ids.p, idsSorted.p, n, 0, 64, c->stream) != hipSuccess)
       return RTHIP_E_ARG;
-    hipLaunchKernelGGL(k_lbvh_topology, grid, block, 0, c->stream, codesSorted.p, n, binary.p);
-    HIPCHK(hipGetLastError());
-    // refit: one launch per level of the binary tree, until the root has its box (checked every 8 passes)
-    HIPCHK(hipMemsetAsync(done.p, 0, n - 1, c->stream));
-    bool rooted = false;
-    for (uint32_t pass = 1; pass <= 200 && !rooted; ++pass)
+    uint32_t binaryRoot = 0;
+    if (!ploc)
     {
-      hipLaunchKernelGGL(k_lbvh_refit, dim3((n - 1 + kBlock - 1) / kBlock), block, 0, c->stream, binary.p, n - 1, primBoxes.p, idsSorted.p, innerBoxes.p, done.p, pass);
+      hipLaunchKernelGGL(k_lbvh_topology, grid, block, 0, c->stream, codesSorted.p, n, binary.p);
       HIPCHK(hipGetLastError());
-      if ((pass & 7u) == 0)
+      // refit: one launch per level of the binary tree, until the root has its box (checked every 8 passes)
+      HIPCHK(hipMemsetAsync(done.p, 0, n - 1, c->stream));
+      bool rooted = false;
+      for (uint32_t pass = 1; pass <= 200 && !rooted; ++pass)
       {
-        uint8_t flag = 0;
-        HIPCHK(hipMemcpyAsync(&flag, done.p, 1, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        rooted = flag != 0;
+        hipLaunchKernelGGL(k_lbvh_refit, dim3((n - 1 + kBlock - 1) / kBlock), block, 0, c->stream, binary.p, n - 1, primBoxes.p, idsSorted.p, innerBoxes.p, done.p, pass);
+        HIPCHK(hipGetLastError());
+        if ((pass & 7u) == 0)
+        {
+          uint8_t flag = 0;
+          HIPCHK(hipMemcpyAsync(&flag, done.p, 1, hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(hipStreamSynchronize(c->stream));
+          rooted = flag != 0;
+        }
       }
+      if (!rooted)
+        return RTHIP_E_LIMIT; // deeper than any tree the traversal stack could take
     }
-    if (!rooted)
-      return RTHIP_E_LIMIT; // deeper than any tree the traversal stack could take
+    else
+    {
+      // PLOC: the Morton-ordered clusters merge with their nearest neighbours round after round (see rt_lbvh.h)
+      HIPCHK(hipMemsetAsync(small.p + kSmallBinary, 0, sizeof(uint32_t), c->stream));
+      hipLaunchKernelGGL(k_ploc_init, grid, block, 0, c->stream, primBoxes.p, idsSorted.p, n, clusterRefA.p, clusterBoxA.p);
+      HIPCHK(hipGetLastError());
+      uint32_t count = n;
+      uint32_t *refIn = clusterRefA.p, *refOut = clusterRefB.p;
+      LbvhBox *boxIn = clusterBoxA.p, *boxOut = clusterBoxB.p;
+      for (uint32_t round = 0; count > 1; ++round)
+      {
+        if (round > 4096)
+          return RTHIP_E_LIMIT; // (every round merges at least the closest pair: n rounds at the very worst)
+        const dim3 g((count + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_ploc_nearest, g, block, 0, c->stream, boxIn, count, radius, nearest.p);
+        hipLaunchKernelGGL(k_ploc_merge, g, block, 0, c->stream, refIn, boxIn, count, nearest.p, small.p + kSmallBinary, binary.p, innerBoxes.p, flags.p);
+        HIPCHK(hipGetLastError());
+        size_t scanNow = scanTemp.n;
+        if (rocprim::exclusive_scan(scanTemp.p, scanNow, flags.p, offsets.p, 0u, count, rocprim::plus<uint32_t>(), c->stream) != hipSuccess)
+          return RTHIP_E_ARG;
+        hipLaunchKernelGGL(k_ploc_compact, g, block, 0, c->stream, refIn, boxIn, flags.p, offsets.p, count, refOut, boxOut, small.p + kSmallClusters);
+        HIPCHK(hipGetLastError());
+        uint32_t next = 0;
+        HIPCHK(hipMemcpyAsync(&next, small.p + kSmallClusters, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (next == 0 || next >= count)
+          return RTHIP_E_LIMIT; // cannot happen (the globally closest pair is mutual); guards the loop
+        count = next;
+        std::swap(refIn, refOut), std::swap(boxIn, boxOut);
+      }
+      HIPCHK(hipMemcpy(&binaryRoot, refIn, sizeof(uint32_t), hipMemcpyDeviceToHost));
+      if (binaryRoot & 0x80000000u)
+        return RTHIP_E_ARG; // n > maxLeaf >= 1 triangles always end in an inner node
+    }
     // collapse to 4-wide nodes, one launch per level of the wide tree
     const uint32_t root = nodesUsed;
     if (root >= nodeCap)
@@ -1262,14 +1352,14 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
       init[0] = root + 1; // next free node
       init[2] = 1;        // level 0 holds the root
       HIPCHK(hipMemcpyAsync(small.p, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-      const uint2 first = make_uint2(0u, root);
+      const uint4 first = make_uint4(binaryRoot, root, 0u, 0u);
       HIPCHK(hipMemcpyAsync(frontier.p, &first, sizeof(first), hipMemcpyHostToDevice, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream)); // (the two host sources above are stack / local memory)
     }
     LbvhEmitArgs ea;
     ea.nodes = binary.p, ea.innerBoxes = innerBoxes.p, ea.primBoxes = primBoxes.p, ea.ids = idsSorted.p;
     ea.out = c->nodes.p, ea.outCapacity = nodeCap, ea.nodeCounter = small.p, ea.overflow = small.p + 1;
-    ea.recordBase = base, ea.maxLeaf = maxLeaf;
+    ea.recordBase = base, ea.maxLeaf = maxLeaf, ea.order = order.p, ea.traversalCost = c->buildTraversalCost;
     for (uint32_t level = 0; level <= kLevels; ++level)
     {
       ea.frontierIn = frontier.p + (size_t)(level & 1u) * largest;
@@ -1279,7 +1369,7 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
       hipLaunchKernelGGL(k_lbvh_emit, dim3(std::min<uint32_t>((n + kBlock - 1) / kBlock, (uint32_t)c->numCUs * 8u)), block, 0, c->stream, ea);
       HIPCHK(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_lbvh_gather, grid, block, 0, c->stream, trisIn.p + base, idsSorted.p, n, c->tris.p + base);
+    hipLaunchKernelGGL(k_lbvh_gather, grid, block, 0, c->stream, trisIn.p + base, order.p, n, c->tris.p + base);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> fin(2 + kLevels + 2, 0u);
     HIPCHK(hipMemcpyAsync(fin.data(), small.p, fin.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1331,6 +1421,77 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
   c->alt.spill.release();
   c->sceneEpoch++;
   c->haveScene = true;
+  return 0;
+}
+
+// Moved vertices, same topology: the records take the new operands and every box of the triangle-level tree is recomputed
+// bottom-up (one launch per level, as many as the tree is deep).  No counterpart in the reference, whose CPU path has no
+// triangle-level tree to keep up to date.
+int rthip_refit(rthip_ctx* c, const rtflat_model_node* modelNodes, const rtflat_tri* trisModelOrder, float* msOut)
+{
+  if (!c || !modelNodes || !trisModelOrder)
+    return RTHIP_E_ARG;
+  if (!c->haveScene)
+    return RTHIP_E_STATE;
+  HIPCHK(hipSetDevice(c->device));
+  // frames still in flight on either slot read the scene
+  HIPCHK(hipStreamSynchronize(c->alt.stream));
+  HIPCHK(hipStreamSynchronize(c->alt.stream2));
+  HIPCHK(hipStreamSynchronize(c->stream2));
+  c->altPending = false;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const uint32_t numTris = c->info.numTris, numNodes = c->info.numNodes, numModelNodes = c->info.numModelNodes;
+  DevBuf<rtflat_tri> incoming;
+  DevBuf<rtflat_model_node> incomingModels;
+  DevBuf<LbvhBox> nodeBoxes;
+  DevBuf<uint8_t> done;
+  DevBuf<uint32_t> flag;
+  int rc;
+  if ((rc = incoming.ensure(numTris)) || (rc = incomingModels.ensure(numModelNodes)) || (rc = nodeBoxes.ensure(numNodes)) || (rc = done.ensure(numNodes)) ||
+      (rc = flag.ensure(1)))
+    return rc;
+  HIPCHK(hipMemcpy(incoming.p, trisModelOrder, sizeof(rtflat_tri) * numTris, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(incomingModels.p, modelNodes, sizeof(rtflat_model_node) * numModelNodes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), c->stream));
+  HIPCHK(hipMemsetAsync(done.p, 0, numNodes, c->stream));
+  HIPCHK(hipEventRecord(c->evA, c->stream));
+  const float3 lo = make_float3(c->info.sceneLo[0], c->info.sceneLo[1], c->info.sceneLo[2]), hi = make_float3(c->info.sceneHi[0], c->info.sceneHi[1], c->info.sceneHi[2]);
+  // How far may the triangles move?  The padding of every box (padAbs) was sized for coordinates up to `reach` = |centre| +
+  // originBound + diagonal (BvhFlattener.cpp): vertices anywhere within one scene diagonal of the flattened box stay inside it,
+  // and so do the "effective" triangles the reference's edge indexing makes of another triangle's edges.
+  const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+  const float slack = std::sqrt(dx * dx + dy * dy + dz * dz);
+  hipLaunchKernelGGL(k_refit_tris, dim3((numTris + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->tris.p, incoming.p, numTris, c->info.padAbs,
+                     make_float3(lo.x - slack, lo.y - slack, lo.z - slack), make_float3(hi.x + slack, hi.y + slack, hi.z + slack), flag.p);
+  HIPCHK(hipGetLastError());
+  for (uint32_t pass = 1; pass <= c->info.maxDepthBlas + 1; ++pass)
+  {
+    hipLaunchKernelGGL(k_refit_nodes, dim3((numNodes + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->nodes.p, numNodes, c->tris.p, c->info.padAbs, nodeBoxes.p,
+                       done.p, pass);
+    HIPCHK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_refit_model_boxes, dim3((numModelNodes + 63) / 64), dim3(64), 0, c->stream, c->modelNodes.p, incomingModels.p, numModelNodes);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(c->evB, c->stream));
+  uint32_t outside = 0;
+  HIPCHK(hipMemcpyAsync(&outside, flag.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (msOut)
+    HIPCHK(hipEventElapsedTime(msOut, c->evA, c->evB));
+  c->sceneEpoch++; // (the traversal-mode measurement is taken again: the rays may behave differently now)
+  if (outside)
+  {
+    c->haveScene = false; // the records have been overwritten; the caller flattens and uploads again
+    return RTHIP_E_BOUNDS;
+  }
+  return 0;
+}
+
+int rthip_set_build_quality(rthip_ctx* c, int quality)
+{
+  if (!c || quality < 0 || quality > 1)
+    return RTHIP_E_ARG;
+  c->buildQuality = quality;
   return 0;
 }
 

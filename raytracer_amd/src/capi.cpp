@@ -240,7 +240,10 @@ int rt_set_option(rt_renderer* r, const char* name, double value)
   else if (n == "buildThreads")
     fo.threads = u;
   else if (n == "deviceBvh")
+  {
     fo.deviceBuild = value != 0;
+    fo.deviceBuildQuality = value == 2 ? 1 : 0; // 1: Morton LBVH (default), 2: PLOC over the Morton order
+  }
   else if (n == "materials")
     r->hip->getScene()->shading.materials = value != 0;
   else if (n == "pointShadows")

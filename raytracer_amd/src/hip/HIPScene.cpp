@@ -96,6 +96,9 @@ void HIPScene::createRayTracingHierarchy()
     // the flattener stopped before the triangle-level build: the device builds it from the records in pool order, and the
     // host copy of the scene is completed from what it built (the oracle-side tests and the CPU baseline walk that copy)
     float ms = 0.0f;
+    error = rthip_set_build_quality(ctx, options.deviceBuildQuality);
+    if (error)
+      return;
     error = rthip_upload_scene_build(ctx, &flat.info, flat.modelNodes.data(), flat.tris.data(), options.maxLeafTriangles, dl,
                                      (uint32_t)directionalLights.size(), pl, (uint32_t)pointLights.size(), &ms);
     if (error)

@@ -31,6 +31,7 @@ struct FlattenOptions
   // true: stop before step 2 -- the triangle-level BVH is built on the device (rthip_upload_scene_build); the records of
   // step 3 are then written in the order of the scene's pools and the node array holds a single childless node
   bool deviceBuild = false;
+  int deviceBuildQuality = 0;  // rthip_set_build_quality: 0 = Morton LBVH, 1 = PLOC (option deviceBvh = 1 / 2)
 };
 
 struct FlatScene

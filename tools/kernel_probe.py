@@ -48,8 +48,8 @@ def main():
         c = r.counters()
         rays = c["extendPrimary"] + c["extendSecondary"] + c["shadow"]
         mode, cal = r.refill_mode()
-        print("%s pipelining=%d: %.3f ms per frame, %.1f Mrays/s   (traversal mode %d, list launches on %d blocks per CU; calibration low/high/packet %.3f / %.3f / %.3f ms)" % (
-            name, pipelining, ms, rays / ms / 1e3, mode, r.grid_blocks(), cal[0], cal[1], cal[2]), flush=True)
+        print("%s pipelining=%d: %.3f ms per frame, %.1f Mrays/s   (traversal mode %d, list launches on %d blocks per CU; calibration low/high/packet/camera-packet %.3f / %.3f / %.3f / %.3f ms; build host %.2f s device %.1f ms, %d nodes)" % (
+            name, pipelining, ms, rays / ms / 1e3, mode, r.grid_blocks(), cal[0], cal[1], cal[2], cal[3], *r.build_times(), int(r.flat()["info"].numNodes)), flush=True)
         if not pipelining:
             r.set_option("kernelTiming", 1)
             r.begin_frame(cam, W, H, N)
