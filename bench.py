@@ -279,6 +279,9 @@ def main():
     ap.add_argument("--tile-batch", type=int, default=16, help="--dynamic: tiles taken from the cursor at a time")
     ap.add_argument("--no-roofline", action="store_true", help="skip the extra instrumented frames (used under rocprofv3 --pmc)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the bounded CPU-baseline sample")
+    ap.add_argument("--bvh", choices=("device", "host"), default="device",
+                    help="which builder makes the triangle-level BVH of the timed frames: the device's (Morton LBVH + SAH leaves, "
+                         "milliseconds) or the host's binned SAH (seconds); the other one is rendered untimed afterwards as the A/B")
     ap.add_argument("--torch-gather", action="store_true", help="N>1: gather with torch.distributed instead of rthip_gather (the C ABI's RCCL gather)")
     args = ap.parse_args()
 
@@ -323,7 +326,9 @@ def main():
     width, height = wl["width"], wl["height"]  # the same frame at every N: strong scaling
     spp, max_depth, ts = wl["spp"], wl["max_depth"], 64
 
-    r = spec.build_product(options=dict(maxDepth=max_depth), device=local_rank)
+    device_built = args.bvh == "device"
+    r = spec.build_product(options=dict(maxDepth=max_depth, deviceBvh=1 if device_built else 0), device=local_rank)
+    build_host_s, build_device_ms = r.build_times()
     flat = r.flat()
     num_tris, num_nodes = int(flat["info"].numTris), int(flat["info"].numNodes)
     assignment = rdist.assign_tiles(width, height, world, ts)
@@ -339,7 +344,7 @@ def main():
     tiles_total = int(sum(len(a) for a in assignment))
     dynamic = args.dynamic and world > 1
     # the C ABI's own RCCL gather (rthip_gather) unless rehearsing over gloo or asked otherwise
-    native_gather = world > 1 and backend == "nccl" and not args.torch_gather and not dynamic
+    native_gather = world > 1 and backend == "nccl" and not args.torch_gather
     per_rank_floats = rdist.padded_tile_count(assignment) * ts * ts * 3
     gathered = None
     gather_note = None
@@ -351,9 +356,13 @@ def main():
             gather_note = "rthip_gather unavailable (%s): gathered with torch.distributed" % e
             if rank == 0:
                 print("bench: " + gather_note, file=sys.stderr, flush=True)
+    dyn_ids = dyn_counts = None
     if native_gather:
-        if rank == 0:
+        if rank == 0 and not dynamic:
             gathered = torch.empty((world, per_rank_floats), dtype=torch.float32, device=dev)
+        if rank == 0 and dynamic:  # rthip_gather_tiles: every rank's tiles, one after the other, whoever rendered them
+            gathered = torch.empty((tiles_total * ts * ts * 3,), dtype=torch.float32, device=dev)
+        dyn_ids, dyn_counts = np.zeros(tiles_total, np.uint32), np.zeros(world, np.uint32)
 
     queue = None
     local_buf = None
@@ -362,7 +371,6 @@ def main():
         local_buf = torch.empty((tiles_total * ts * ts, 3), dtype=torch.float32, device=dev)  # a rank may end up with any number of tiles
     frame_no = [0]
     tile_counts, finish_times = [], []
-    step_rays = np.zeros(4)  # dynamic mode: rays of the current step, summed over its tile batches
 
     stage = recv = None
     pending = []
@@ -392,7 +400,7 @@ def main():
             # frames); the timed region ends with a synchronisation, and a multi-GPU step waits below when it gathers
             r.begin_frame(cam, width, height, spp)
             r.enqueue_passes(0, spp)
-        if native_gather:
+        if native_gather and not dynamic:
             # rthip_gather: the rank's tile-major accumulator goes to rank 0 over RCCL (grouped send/recv), queued on the
             # context's stream behind the frame; rank 0 then re-tiles the gathered buffers into the row-major frame
             t0 = time.perf_counter()
@@ -416,35 +424,45 @@ def main():
             pending.append((dist.gather(src, dst, dst=0, async_op=True), dst, src))
             gather_ms.append((time.perf_counter() - t0) * 1e3)
         if dynamic:
-            # tiles come from the shared cursor in batches; each batch is a frame of its own over just those tiles
+            # Tiles come from the shared cursor in batches and are queued on the context's two slots as they come
+            # (rthip_enqueue_tiles: no host synchronisation); a rank draws again only when fewer than two of its batches are
+            # unfinished (rthip_wait_tiles), which is what sends the work to whoever is fast.  The tiles' pixels line up in the
+            # context's accumulator in arrival order; counters are read once per frame.
             queue.new_frame(frame_no[0])
             frame_no[0] += 1
-            mine, filled = [], 0
-            step_rays[:] = 0
+            r.begin_dynamic(cam, width, height, spp, max_depth)
             while (batch := queue.next_batch()) is not None:
-                r.set_tiles(batch)
-                r.begin_frame(cam, width, height, spp)
-                r.render_passes(0, spp)
-                n = len(batch) * ts * ts * 3
-                rc = hl.rthip_copy_accumulator_to(ctx, local_buf.data_ptr() + filled * 4, n)
-                assert rc == 0, ra.capi.error_string(rc)
-                filled += n
-                mine.extend(int(t) for t in batch)
-                bc = r.counters()
-                step_rays[:] += [bc["extendPrimary"] + bc["extendSecondary"] + bc["shadow"], bc["extendPrimary"], bc["extendSecondary"], bc["shadow"]]
+                r.enqueue_tiles(batch, max_in_flight=2)
+            rc = hl.rthip_wait_tiles(ctx, 0)
+            assert rc == 0, ra.capi.error_string(rc)
             finish_times.append(time.perf_counter())
+            mine = r.local_tiles()
             tile_counts.append(len(mine))
             t0 = time.perf_counter()
-            local = local_buf[: filled // 3]
-            got = rdist.gather_dynamic(local if backend == "nccl" else local.cpu(), mine, rank, world, dist, ts * ts)
-            if rank == 0:
-                for tiles, src in got:
-                    if len(tiles) == 0:
-                        continue
-                    src = src.to(dev).contiguous()
-                    rc = hl.rthip_untile(ctx, src.data_ptr(), ra.capi._up(tiles), len(tiles), full_frame.data_ptr())
+            if native_gather:
+                # rthip_gather_tiles: header [count | tile ids] + exactly the pixels each rank holds, grouped ncclSend / ncclRecv
+                rc = hl.rthip_gather_tiles(ctx, gathered.data_ptr() if rank == 0 else None, gathered.numel() if rank == 0 else 0,
+                                           ra.capi._up(dyn_ids), tiles_total, ra.capi._up(dyn_counts), 0)
+                assert rc == 0, ra.capi.error_string(rc)
+                if rank == 0:
+                    n_all = int(dyn_counts.sum())
+                    assert n_all == tiles_total, "every tile is rendered exactly once: %d of %d arrived" % (n_all, tiles_total)
+                    rc = hl.rthip_untile(ctx, gathered.data_ptr(), ra.capi._up(dyn_ids), n_all, full_frame.data_ptr())
                     assert rc == 0, ra.capi.error_string(rc)
-            torch.cuda.synchronize()
+            else:
+                # rehearsal over gloo (several ranks on one GPU): the same frame through torch.distributed
+                rc = hl.rthip_copy_accumulator_to(ctx, local_buf.data_ptr(), tiles_total * ts * ts * 3)
+                assert rc == 0, ra.capi.error_string(rc)
+                local = local_buf[: len(mine) * ts * ts]
+                got = rdist.gather_dynamic(local if backend == "nccl" else local.cpu(), mine, rank, world, dist, ts * ts)
+                if rank == 0:
+                    for tiles, src in got:
+                        if len(tiles) == 0:
+                            continue
+                        src = src.to(dev).contiguous()
+                        rc = hl.rthip_untile(ctx, src.data_ptr(), ra.capi._up(tiles), len(tiles), full_frame.data_ptr())
+                        assert rc == 0, ra.capi.error_string(rc)
+                torch.cuda.synchronize()
             gather_ms.append((time.perf_counter() - t0) * 1e3)
 
     def sync_all():
@@ -471,8 +489,6 @@ def main():
     cnt = r.counters()  # totals of the LAST frame (begin_frame resets them)
     _mode, _cal = r.refill_mode()
     _grid = r.grid_blocks()
-    if dynamic:
-        cnt = {"extendPrimary": step_rays[1], "extendSecondary": step_rays[2], "shadow": step_rays[3]}
     rays_local = cnt["extendPrimary"] + cnt["extendSecondary"] + cnt["shadow"]
     t = torch.tensor([elapsed, float(rays_local), float(cnt["extendPrimary"]), float(cnt["extendSecondary"]), float(cnt["shadow"])],
                      dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -490,7 +506,7 @@ def main():
         everyone = [None] * world
         dist.all_gather_object(everyone, mine_stats)
         ends = np.array([e[1] for e in everyone], dtype=np.float64)  # [rank][step]
-        balance = {"tiles_per_rank_last_step": [int(e[0]) for e in everyone], "tile_batch": args.tile_batch,
+        balance = {"tiles_per_rank_last_step": [int(e[0]) for e in everyone], "tile_batch": args.tile_batch, "batches_in_flight_per_rank": 2,
                    "idle_tail_ms_mean": round(float(np.mean(ends.max(0) - ends.min(0)) * 1e3), 4) if ends.size else None}
         r.set_tiles(assignment[rank])
     value = rays_frame / (ms_per_step * 1e-3) / 1e6
@@ -546,25 +562,31 @@ def main():
     roofline = roofline_block(args.workload, ktimes, wc, spp, ktimes_alone, 64 * (num_tris + num_nodes))
 
     # ---- the same scene through the DEVICE-built BVH (rthip_upload_scene_build): build time and frame time, untimed extra
-    device_bvh = None
+    # ---- the same scene through the OTHER builder (untimed extra): its build time and frame time, the A/B of --bvh
+    def builder_block(device, host_s, device_ms, nodes, ms):
+        return {"builder": "device: Morton LBVH (bits dealt longest-extent-first) + SAH leaves, rthip_upload_scene_build" if device
+                else "host: binned SAH, BvhFlattener.cpp", "build_ms_on_device": round(device_ms, 3) if device else None,
+                "host_seconds": round(host_s, 3), "bvh_nodes": int(nodes), "ms_per_step": round(ms, 4)}
+    bvh_used = builder_block(device_built, build_host_s, build_device_ms, num_nodes, ms_per_step)
+    bvh_other = None
     if world == 1:
         flat = dict(flat, model_nodes=flat["model_nodes"].copy(), nodes=flat["nodes"].copy(), tris=flat["tris"].copy(), _owner=None)
         r.close()
-        r2 = spec.build_product(options=dict(maxDepth=max_depth, deviceBvh=1), device=local_rank)
+        r2 = spec.build_product(options=dict(maxDepth=max_depth, deviceBvh=0 if device_built else 1), device=local_rank)
         host_s, device_ms = r2.build_times()
         f2 = r2.flat()["info"]
         for _ in range(2):
             r2.begin_frame(cam, width, height, spp)
             r2.enqueue_passes(0, spp)
         r2.synchronize()
+        reps = 3 if ms_per_step > 50 else 10
         t1 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(reps):
             r2.begin_frame(cam, width, height, spp)
             r2.enqueue_passes(0, spp)
         r2.synchronize()
-        device_bvh = {"build_ms_on_device": round(device_ms, 3), "host_flatten_seconds": round(host_s, 3), "bvh_nodes": int(f2.numNodes),
-                      "ms_per_step": round((time.perf_counter() - t1) / 3 * 1e3, 4),
-                      "note": "Morton LBVH built on the GPU; the timed steps above use the host's binned-SAH tree (better tree, slower build)"}
+        bvh_other = builder_block(not device_built, host_s, device_ms, f2.numNodes, (time.perf_counter() - t1) / reps * 1e3)
+        bvh_other["frame_time_ratio_used_over_this"] = round(ms_per_step / bvh_other["ms_per_step"], 4)
         r2.close()
 
     cpu = None
@@ -580,7 +602,7 @@ def main():
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": wl["name"], "width": width, "height": height, "spp": spp, "max_depth": max_depth,
-                      "tris": num_tris, "bvh_nodes": num_nodes, "bvh_build_seconds": round(float(flat["build_seconds"]), 3), "device_bvh": device_bvh,
+                      "tris": num_tris, "bvh_nodes": num_nodes, "bvh": bvh_used, "bvh_other_builder": bvh_other,
                       "rays_per_step": int(rays_frame), "primary": int(t[2]), "secondary_extend": int(t[3]), "shadow": int(t[4]),
                       "parallelism": (f"tiles64-{'dynamic' if dynamic else 'rr'}-x{world}-{backend}-{'rthip_gather' if native_gather else 'torch_gather'}"
                                       if world > 1 else "single"),

@@ -199,6 +199,34 @@ int rthip_comm_init(rthip_ctx* ctx, const unsigned char id[RTHIP_COMM_ID_BYTES],
 int rthip_comm_destroy(rthip_ctx* ctx);
 int rthip_gather(rthip_ctx* ctx, float* recvDev, uint64_t floatsPerRank, int root);
 
+/* Dynamic tile ownership (BASELINE configs[4]: "dynamic tile rebalancing"): the ranks draw tiles from a shared
+ * cursor while the frame renders, so a rank whose tiles were cheap takes more.  The cursor is the host's business (any atomic
+ * counter every rank can reach; raytracer_amd/dist.py uses a torch.distributed store); the C ABI carries the rest.  A whole tile
+ * -- all its sample passes -- is rendered by one rank, so per-pixel accumulation order, and with it every bit of the frame, is
+ * what a single GPU produces (src/cpu/CPURenderer.cpp:197).  No counterpart in the reference (one process).
+ *  rthip_begin_dynamic:  a frame whose tiles are not known yet.  frame->numTiles = the most tiles this rank may end up with
+ *                        (0 = all tiles of the image; buffers are sized for it), frame->tileIds is ignored, aovDepths must be 0.
+ *  rthip_enqueue_tiles:  queues ALL sample passes of these tiles on the context's streams and returns (no host synchronisation;
+ *                        consecutive calls alternate between the two sets of path buffers, so two tile batches are in flight).
+ *                        The tiles' pixels follow those of earlier calls in the context's tile-major accumulator.
+ *  rthip_wait_tiles:     blocks until at most maxInFlight rthip_enqueue_tiles calls are unfinished: the back-pressure that makes
+ *                        the drawing dynamic (a rank asks the cursor for more only when it is about to run dry; 2 keeps both slots busy).
+ *  rthip_get_local_tiles: the tile ids this context holds pixels for, in accumulator order (static frames: the frame's tile list).
+ *  rthip_gather_tiles:   the assembly for variable ownership: every rank sends a header [count | tile ids] and then exactly its
+ *                        tiles' pixels (grouped ncclSend / ncclRecv on the context's stream); on root, rank k's pixels follow rank
+ *                        k-1's in recvDev (device memory, recvCapacityFloats >= all tiles of the frame x tileSize^2 x 3),
+ *                        tileIdsOut (host, tileIdCapacity >= all tiles) lists the tiles in the same order and tileCountsOut
+ *                        (host, worldSize entries) says how many each rank brought; one rthip_untile(recvDev, tileIdsOut, total)
+ *                        then writes the frame.  The root reads the headers back (one synchronisation per frame); other ranks
+ *                        only enqueue.  Capacities too small for the frame are the caller's error on EVERY rank (checked on root
+ *                        before any pixel is posted, but the other ranks' sends then never complete). */
+int rthip_begin_dynamic(rthip_ctx* ctx, const rthip_camera* camera, const rthip_frame_desc* frame);
+int rthip_enqueue_tiles(rthip_ctx* ctx, const uint32_t* tileIds, uint32_t numTiles);
+int rthip_wait_tiles(rthip_ctx* ctx, uint32_t maxInFlight);
+int rthip_get_local_tiles(rthip_ctx* ctx, uint32_t* tileIdsOut, uint32_t capacity, uint32_t* countOut);
+int rthip_gather_tiles(rthip_ctx* ctx, float* recvDev, uint64_t recvCapacityFloats, uint32_t* tileIdsOut, uint32_t tileIdCapacity,
+                       uint32_t* tileCountsOut, int root);
+
 int rthip_get_counters(rthip_ctx* ctx, rthip_counters* out); /* totals since rthip_begin */
 /* 1: count nodesVisited/trisTested in the traversal kernels (slower); 0: off (default) */
 int rthip_set_work_counting(rthip_ctx* ctx, int enabled);

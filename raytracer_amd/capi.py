@@ -119,6 +119,11 @@ def hip_lib():
         L.rthip_refit.argtypes = [vp, vp, vp, fp]
         L.rthip_download_scene.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
         L.rthip_begin.argtypes = [vp, C.POINTER(Camera), C.POINTER(FrameDesc)]
+        L.rthip_begin_dynamic.argtypes = [vp, C.POINTER(Camera), C.POINTER(FrameDesc)]
+        L.rthip_enqueue_tiles.argtypes = [vp, up, C.c_uint32]
+        L.rthip_wait_tiles.argtypes = [vp, C.c_uint32]
+        L.rthip_get_local_tiles.argtypes = [vp, up, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.rthip_gather_tiles.argtypes = [vp, vp, C.c_uint64, up, C.c_uint32, up, C.c_int]
         L.rthip_set_refill_mode.argtypes = [vp, C.c_int]
         L.rthip_get_refill_mode.argtypes = [vp, C.POINTER(C.c_int), fp]
         L.rthip_get_grid_blocks.argtypes = [vp, C.POINTER(C.c_uint32)]
@@ -454,6 +459,28 @@ class Renderer:
 
         texels = view(tx, 3 * nt.value, np.dtype("<f4")).reshape(-1, 3) if tx.value else np.zeros((0, 3), np.float32)
         return dict(_owner=self, shade=view(sh, n_tris, SHADE_DTYPE), materials=view(mt, nm.value, MATERIAL_DTYPE), texels=texels)
+
+    # ---- dynamic tile ownership (include/rthip.h: rthip_begin_dynamic / rthip_enqueue_tiles / rthip_wait_tiles)
+    def begin_dynamic(self, camera, width, height, num_samples, max_depth, capacity=0, tile_size=64):
+        """A frame whose tiles arrive while it renders (at most `capacity` of them on this rank; 0 = all tiles of the image)."""
+        self._size = (int(height), int(width))
+        d = FrameDesc(int(width), int(height), int(num_samples), int(max_depth), 0, int(tile_size), int(capacity), 0, None)
+        _check(hip_lib().rthip_begin_dynamic(self.context, C.byref(camera), C.byref(d)), "rthip_begin_dynamic")
+
+    def enqueue_tiles(self, tile_ids, max_in_flight=None):
+        """Queues every sample pass of these tiles (no waiting); with max_in_flight, then blocks until at most that many such
+        calls are unfinished -- the back-pressure that makes drawing tiles from a shared cursor balance the ranks."""
+        t = np.ascontiguousarray(tile_ids, np.uint32)
+        _check(hip_lib().rthip_enqueue_tiles(self.context, _up(t), t.size), "rthip_enqueue_tiles")
+        if max_in_flight is not None:
+            _check(hip_lib().rthip_wait_tiles(self.context, int(max_in_flight)), "rthip_wait_tiles")
+
+    def local_tiles(self):
+        n = C.c_uint32(0)
+        _check(hip_lib().rthip_get_local_tiles(self.context, None, 0, C.byref(n)), "rthip_get_local_tiles")
+        ids = np.zeros(max(1, n.value), np.uint32)
+        _check(hip_lib().rthip_get_local_tiles(self.context, _up(ids), ids.size, C.byref(n)), "rthip_get_local_tiles")
+        return ids[: n.value]
 
     def refit(self, moved):
         """rthip_refit: the scene takes the vertex positions of `moved` -- a renderer (any backend, "hip-offline" will do) holding

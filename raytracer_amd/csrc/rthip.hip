@@ -254,6 +254,17 @@ struct rthip_ctx
   uint32_t pipelineBatches = 2;  // 2: batches alternate between the two slots (two in flight); 0 = one slot only
   uint32_t batchToggle = 0;      // which slot the next batch goes to (alternates across calls and frames)
   bool framePipelined = false;   // decided by rthip_begin (both slots sized for the frame's batches)
+  // dynamic tile ownership (rthip_begin_dynamic / rthip_enqueue_tiles): the frame's tiles arrive while it renders
+  bool dynamic = false;
+  uint32_t dynCapacity = 0, dynCount = 0; // most tiles this frame may take / taken so far
+  std::vector<uint32_t> dynIds;           // their ids, in arrival order (== the order of their blocks in the accumulator)
+  DevBuf<uint32_t> dynTable;              // 2 x capacity tile origins: one table per frame parity (two frames may be in flight)
+  uint32_t* dynStage = nullptr;           // pinned host staging of the same shape (the uploads are truly asynchronous)
+  size_t dynStageWords = 0;
+  static constexpr uint32_t kDynEvents = 8;
+  hipEvent_t dynEvents[kDynEvents] = {};  // one per rthip_enqueue_tiles call, round robin: rthip_wait_tiles' back-pressure
+  uint64_t dynIssued = 0, dynRetired = 0;
+  DevBuf<uint32_t> gatherHdr;             // rthip_gather_tiles: [count | tile ids] per rank
   // multi-GPU assembly (rthip_comm_init / rthip_gather)
   ncclComm_t comm = nullptr;
   int commRank = 0, commSize = 0;
@@ -836,7 +847,9 @@ int calibrateRefill(rthip_ctx* c)
   return 0;
 }
 
-int renderPasses(rthip_ctx* c, uint32_t sampBegin, uint32_t count, bool sync)
+// tileFirst / tileCount: the local tiles to render (dynamic frames render the tiles of one rthip_enqueue_tiles call); the whole
+// local tile list by default
+int renderPasses(rthip_ctx* c, uint32_t sampBegin, uint32_t count, bool sync, uint32_t tileFirst = 0, uint32_t tileCount = ~0u)
 {
   if (!c->haveScene || !c->haveFrame)
     return RTHIP_E_STATE;
@@ -848,19 +861,37 @@ int renderPasses(rthip_ctx* c, uint32_t sampBegin, uint32_t count, bool sync)
   // the other's.  Nothing joins the slots at the end of the call; only the accumulate kernels are chained (per-pixel sums
   // stay in sample order).
   const bool pipelined = c->framePipelined;
-  const BatchPlan bp = planBatches(c, count, c->geom, c->aovDepths, pipelined);
-  const bool fresh = c->accFresh; // first call of the frame: its batches cover every local pixel once per sample range
+  if (tileCount == ~0u)
+    tileCount = c->geom.numLocalTiles - std::min(tileFirst, c->geom.numLocalTiles);
+  if (tileCount == 0 || (uint64_t)tileFirst + tileCount > c->geom.numLocalTiles)
+    return RTHIP_E_ARG;
+  FrameGeom range = c->geom; // (planning only: how the tiles of this call are cut into batches)
+  range.numLocalTiles = tileCount;
+  const BatchPlan bp = planBatches(c, count, range, c->aovDepths, pipelined);
+  // first call of the frame: its batches cover every local pixel once per sample range; in a dynamic frame every call brings
+  // tiles that have not been rendered yet
+  const bool fresh = c->accFresh || c->dynamic;
+  const uint32_t tileEnd = tileFirst + tileCount;
   for (uint32_t done = 0; done < count; done += bp.samples)
   {
     const uint32_t n = std::min(bp.samples, count - done);
-    for (uint32_t t0 = 0; t0 < c->geom.numLocalTiles; t0 += bp.tiles)
+    for (uint32_t t0 = tileFirst; t0 < tileEnd; t0 += bp.tiles)
     {
-      const uint32_t nt = std::min(bp.tiles, c->geom.numLocalTiles - t0);
+      const uint32_t nt = std::min(bp.tiles, tileEnd - t0);
       const bool useAlt = pipelined && (c->batchToggle++ & 1u);
       if (useAlt)
         swapSlot(c);
       hipEvent_t after = (c->lastAcc && c->lastAccStream != c->stream) ? c->lastAcc : nullptr;
-      int rc = renderBatch(c, sampBegin + done, n, t0, nt, fresh && done == 0, after);
+      int rc = 0;
+      if (c->dynamic && done == 0)
+      {
+        // the origins of these tiles go up on the batch's own stream, right ahead of the kernels that read them (pinned
+        // staging: nothing here waits for the device)
+        const size_t off = (size_t)c->frameParity * c->dynCapacity + t0;
+        rc = (int)hipMemcpyAsync(c->dynTable.p + off, c->dynStage + off, sizeof(uint32_t) * nt, hipMemcpyHostToDevice, c->stream);
+      }
+      if (!rc)
+        rc = renderBatch(c, sampBegin + done, n, t0, nt, fresh && done == 0, after);
       if (!rc)
         rc = (int)hipEventRecord(c->evDone, c->stream);
       c->lastAcc = c->evDone;
@@ -1078,6 +1109,11 @@ int rthip_destroy(rthip_ctx* c)
     (void)hipEventDestroy(e);
   dropEvent(c->evFork), dropEvent(c->evJoin), dropEvent(c->evDone), dropEvent(c->evFrame);
   dropEvent(c->alt.evFork), dropEvent(c->alt.evJoin), dropEvent(c->alt.evDone);
+  for (hipEvent_t& e : c->dynEvents)
+    dropEvent(e);
+  if (c->dynStage)
+    (void)hipHostFree(c->dynStage);
+  c->dynStage = nullptr;
   delete c; // the DevBuf members free their device memory
   return 0;
 }
@@ -1679,6 +1715,7 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
   g.tileShift = (uint32_t)__builtin_ctz(ts);
   g.batchSamples = 1, g.batchMagic = 0; // set per batch (renderBatch)
   c->hostTileIds.swap(tileIds);
+  c->dynamic = false; // (rthip_begin_dynamic sets it again after this call)
   c->geom = g;
   c->camera = *camera;
   c->maxDepth = f->maxDepth;
@@ -1706,6 +1743,130 @@ int rthip_begin(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc
   {
     c->haveFrame = false; // the frame is not usable: the caller begins again
     return rcCal;
+  }
+  return 0;
+}
+
+// ---- dynamic tile ownership (BASELINE configs[4]): the tiles a rank renders are not known when the frame
+// begins; they arrive in batches from a cursor shared by all ranks (any host-side atomic: raytracer_amd/dist.py TileQueue).
+int rthip_begin_dynamic(rthip_ctx* c, const rthip_camera* camera, const rthip_frame_desc* f)
+{
+  if (!c || !camera || !f || f->width == 0 || f->height == 0)
+    return RTHIP_E_ARG;
+  if (f->aovDepths)
+    return RTHIP_E_ARG; // AOV planes are indexed by a fixed local pixel order
+  const uint32_t ts = f->tileSize ? f->tileSize : 64u;
+  if (ts < 8u || (ts & (ts - 1u)))
+    return RTHIP_E_ARG;
+  const uint64_t allTiles = (uint64_t)((f->width + ts - 1) / ts) * ((f->height + ts - 1) / ts);
+  const uint32_t cap = f->numTiles ? f->numTiles : (uint32_t)allTiles;
+  if (cap == 0 || cap > allTiles)
+    return RTHIP_E_ARG;
+  // sized (and, the first time, calibrated) like a static frame over the first `cap` tiles
+  std::vector<uint32_t> identity(cap);
+  for (uint32_t k = 0; k < cap; ++k)
+    identity[k] = k;
+  rthip_frame_desc g = *f;
+  g.numTiles = cap;
+  g.tileIds = identity.data();
+  if (int rc = rthip_begin(c, camera, &g))
+    return rc;
+  if (c->dynTable.n < 2 * (size_t)cap || c->dynStageWords < 2 * (size_t)cap)
+  {
+    // a larger table: nothing may still be reading the old one
+    HIPCHK(hipStreamSynchronize(c->alt.stream));
+    HIPCHK(hipStreamSynchronize(c->alt.stream2));
+    HIPCHK(hipStreamSynchronize(c->stream2));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->altPending = false;
+    if (int rc = c->dynTable.ensure(2 * (size_t)cap))
+    {
+      c->haveFrame = false;
+      return rc;
+    }
+    if (c->dynStage)
+      (void)hipHostFree(c->dynStage);
+    c->dynStage = nullptr, c->dynStageWords = 0;
+    if (hipHostMalloc((void**)&c->dynStage, sizeof(uint32_t) * 2 * (size_t)cap, hipHostMallocDefault) != hipSuccess)
+    {
+      c->haveFrame = false;
+      return RTHIP_E_LIMIT;
+    }
+    c->dynStageWords = 2 * (size_t)cap;
+  }
+  for (hipEvent_t& e : c->dynEvents)
+    if (!e)
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  c->dynamic = true;
+  c->dynCapacity = cap;
+  c->dynCount = 0;
+  c->dynIds.clear();
+  c->geom.tileXY = c->dynTable.p + (size_t)c->frameParity * cap;
+  c->accFresh = false; // every tile batch starts its own pixels from zero (k_accumulate's `fresh`)
+  return 0;
+}
+
+int rthip_enqueue_tiles(rthip_ctx* c, const uint32_t* tileIds, uint32_t numTiles)
+{
+  if (!c || !tileIds || !numTiles)
+    return RTHIP_E_ARG;
+  if (!c->haveScene || !c->haveFrame || !c->dynamic)
+    return RTHIP_E_STATE;
+  if ((uint64_t)c->dynCount + numTiles > c->dynCapacity)
+    return RTHIP_E_LIMIT;
+  const uint32_t ts = c->geom.tileSize, tilesX = c->geom.tilesX, tilesY = (c->geom.height + ts - 1) / ts;
+  for (uint32_t k = 0; k < numTiles; ++k)
+    if (tileIds[k] >= tilesX * tilesY)
+      return RTHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  // the ring of completion events is finite: retire the oldest call first when it is full
+  if (c->dynIssued - c->dynRetired >= rthip_ctx::kDynEvents)
+  {
+    HIPCHK(hipEventSynchronize(c->dynEvents[c->dynRetired % rthip_ctx::kDynEvents]));
+    c->dynRetired++;
+  }
+  uint32_t* stage = c->dynStage + (size_t)c->frameParity * c->dynCapacity + c->dynCount;
+  for (uint32_t k = 0; k < numTiles; ++k)
+    stage[k] = ((tileIds[k] % tilesX) * ts) | (((tileIds[k] / tilesX) * ts) << 16);
+  const uint32_t first = c->dynCount;
+  c->dynIds.insert(c->dynIds.end(), tileIds, tileIds + numTiles);
+  c->dynCount += numTiles;
+  if (int rc = renderPasses(c, 0, c->geom.numSamples, false, first, numTiles))
+    return rc;
+  // the call is complete when its last batch is (accumulates are chained, so that one finishes last)
+  HIPCHK(hipEventRecord(c->dynEvents[c->dynIssued % rthip_ctx::kDynEvents], c->lastAccStream));
+  c->dynIssued++;
+  return 0;
+}
+
+int rthip_wait_tiles(rthip_ctx* c, uint32_t maxInFlight)
+{
+  if (!c)
+    return RTHIP_E_ARG;
+  if (!c->dynamic)
+    return RTHIP_E_STATE;
+  HIPCHK(hipSetDevice(c->device));
+  while (c->dynIssued - c->dynRetired > maxInFlight)
+  {
+    HIPCHK(hipEventSynchronize(c->dynEvents[c->dynRetired % rthip_ctx::kDynEvents]));
+    c->dynRetired++;
+  }
+  return 0;
+}
+
+int rthip_get_local_tiles(rthip_ctx* c, uint32_t* tileIdsOut, uint32_t capacity, uint32_t* countOut)
+{
+  if (!c || !countOut)
+    return RTHIP_E_ARG;
+  if (!c->haveFrame)
+    return RTHIP_E_STATE;
+  const std::vector<uint32_t>& ids = c->dynamic ? c->dynIds : c->hostTileIds;
+  *countOut = (uint32_t)ids.size();
+  if (tileIdsOut)
+  {
+    if (capacity < ids.size())
+      return RTHIP_E_ARG;
+    std::copy(ids.begin(), ids.end(), tileIdsOut);
   }
   return 0;
 }
@@ -1787,16 +1948,21 @@ static int settleAccumulator(rthip_ctx* c)
   return 0;
 }
 
+// the tiles the context holds pixels for: all local tiles of a static frame, the ones taken so far of a dynamic one
+static uint32_t localTileCount(const rthip_ctx* c) { return c->dynamic ? c->dynCount : c->geom.numLocalTiles; }
+
 static int readTiled(rthip_ctx* c, const float* tileMajorDev, float* rgbOut)
 {
   const size_t full = (size_t)c->geom.width * c->geom.height * 3;
+  const uint32_t numPixels = localTileCount(c) * c->geom.tileSize * c->geom.tileSize;
+  if (numPixels == 0)
+    return 0;
   int rc = c->rowScratch.ensure(full);
   if (rc)
     return rc;
   // pixels of tiles this context does not own keep the caller's values
   HIPCHK(hipMemcpyAsync(c->rowScratch.p, rgbOut, full * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_untile, dim3((c->geom.numLocalPixels + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->geom, tileMajorDev,
-                     c->rowScratch.p, c->geom.numLocalPixels);
+  hipLaunchKernelGGL(k_untile, dim3((numPixels + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->geom, tileMajorDev, c->rowScratch.p, numPixels);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(rgbOut, c->rowScratch.p, full * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -2023,6 +2189,93 @@ int rthip_gather(rthip_ctx* c, float* recvDev, uint64_t floatsPerRank, int root)
   NCCLCHK(rEnd, "ncclGroupEnd");
   // The send reads the accumulator: a frame queued right behind this one may run its first accumulate on the other slot's
   // stream, so that launch is made to wait for the transfer the way it waits for the previous batch's accumulate.
+  HIPCHK(hipEventRecord(c->evDone, c->stream));
+  c->lastAcc = c->evDone;
+  c->lastAccStream = c->stream;
+  return 0; // queued on the context's stream: rthip_untile / rthip_synchronize order themselves behind it
+}
+
+// Variable tile ownership: every rank sends a header [tile count | tile ids] and then exactly the pixels of the tiles it holds;
+// the root learns the counts from the headers (one read-back) and posts receives of matching sizes.  Works for static frames
+// too (no zero padding travels).
+int rthip_gather_tiles(rthip_ctx* c, float* recvDev, uint64_t recvCapacityFloats, uint32_t* tileIdsOut, uint32_t tileIdCapacity, uint32_t* tileCountsOut, int root)
+{
+  if (!c)
+    return RTHIP_E_ARG;
+  if (!c->comm || !c->haveFrame)
+    return RTHIP_E_STATE;
+  const bool isRoot = c->commRank == root;
+  if (root < 0 || root >= c->commSize || (isRoot && (!recvDev || !tileIdsOut || !tileCountsOut)))
+    return RTHIP_E_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  if (int rc = joinSlots(c)) // the frame's last batches may be on the second slot's stream
+    return rc;
+  if (!c->dynamic)
+    if (int rc = settleAccumulator(c))
+      return rc;
+  const uint32_t ts = c->geom.tileSize, tilesY = (c->geom.height + ts - 1) / ts;
+  const uint32_t maxTiles = c->geom.tilesX * tilesY; // every rank computes the same header length from the frame
+  const uint32_t hdrWords = 1 + maxTiles;
+  const std::vector<uint32_t>& ids = c->dynamic ? c->dynIds : c->hostTileIds;
+  const uint32_t mine = (uint32_t)ids.size();
+  if (int rc = c->gatherHdr.ensure((size_t)hdrWords * (isRoot ? c->commSize + 1 : 1)))
+    return rc;
+  std::vector<uint32_t> hdr(hdrWords, 0u);
+  hdr[0] = mine;
+  std::copy(ids.begin(), ids.end(), hdr.begin() + 1);
+  HIPCHK(hipMemcpyAsync(c->gatherHdr.p, hdr.data(), sizeof(uint32_t) * hdrWords, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream)); // (hdr is a local: the copy must have left it; the frame is finished by now anyway)
+  // phase 1: headers
+  NCCLCHK(rccl().groupStart(), "ncclGroupStart");
+  ncclResult_t r = rccl().send(c->gatherHdr.p, hdrWords, ncclUint32, root, c->comm, c->stream);
+  if (r == ncclSuccess && isRoot)
+    for (int k = 0; k < c->commSize && r == ncclSuccess; ++k)
+      r = rccl().recv(c->gatherHdr.p + (size_t)(k + 1) * hdrWords, hdrWords, ncclUint32, k, c->comm, c->stream);
+  ncclResult_t rEnd = rccl().groupEnd();
+  if (r != ncclSuccess)
+    return commFail(r, "ncclSend/ncclRecv (tile headers)");
+  NCCLCHK(rEnd, "ncclGroupEnd");
+  const uint64_t perTile = (uint64_t)ts * ts * 3;
+  std::vector<uint32_t> all;
+  if (isRoot)
+  {
+    all.resize((size_t)hdrWords * c->commSize);
+    HIPCHK(hipMemcpyAsync(all.data(), c->gatherHdr.p + hdrWords, sizeof(uint32_t) * all.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint64_t total = 0;
+    for (int k = 0; k < c->commSize; ++k)
+    {
+      const uint32_t n = all[(size_t)k * hdrWords];
+      if (n > maxTiles)
+        return RTHIP_E_COMM;
+      total += n;
+    }
+    if (total > tileIdCapacity || total * perTile > recvCapacityFloats)
+      return RTHIP_E_ARG; // (every rank still completes phase 2 below only if the root does: report before anything is posted)
+  }
+  // phase 2: the pixels, rank k's block after rank k-1's
+  NCCLCHK(rccl().groupStart(), "ncclGroupStart");
+  r = ncclSuccess;
+  if (mine)
+    r = rccl().send(c->acc.p, (size_t)mine * perTile, ncclFloat, root, c->comm, c->stream);
+  if (r == ncclSuccess && isRoot)
+  {
+    uint64_t off = 0;
+    for (int k = 0; k < c->commSize && r == ncclSuccess; ++k)
+    {
+      const uint32_t n = all[(size_t)k * hdrWords];
+      tileCountsOut[k] = n;
+      std::copy(all.begin() + (size_t)k * hdrWords + 1, all.begin() + (size_t)k * hdrWords + 1 + n, tileIdsOut + off);
+      if (n)
+        r = rccl().recv(recvDev + off * perTile, (size_t)n * perTile, ncclFloat, k, c->comm, c->stream);
+      off += n;
+    }
+  }
+  rEnd = rccl().groupEnd();
+  if (r != ncclSuccess)
+    return commFail(r, "ncclSend/ncclRecv (tile pixels)");
+  NCCLCHK(rEnd, "ncclGroupEnd");
+  // the send reads the accumulator: the next frame's first accumulate waits for it (as after rthip_gather)
   HIPCHK(hipEventRecord(c->evDone, c->stream));
   c->lastAcc = c->evDone;
   c->lastAccStream = c->stream;
