@@ -557,6 +557,30 @@ __global__ __launch_bounds__(kBlock) void k_refit_nodes(rtflat_node* nodes, uint
   done[i] = (uint8_t)pass;
 }
 
+// the packet kernel's copy of the nodes (FatNode, rt_kernel_common.h): every child plane dequantised in double and rounded
+// outward to float, so a fat box contains the quantised box it stands for
+__global__ __launch_bounds__(kBlock) void k_fatten(const rtflat_node* nodes, uint32_t numNodes, FatNode* fat)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= numNodes)
+    return;
+  const rtflat_node n = nodes[i];
+  FatNode f;
+  for (int a = 0; a < 3; ++a)
+  {
+    const double step = ldexp(1.0, (int)n.exp[a] - 127);
+    for (int k = 0; k < 4; ++k)
+    {
+      const bool used = k < (int)n.numChildren && n.child[k] != RTFLAT_INVALID;
+      f.plane[2 * a][k] = used ? __double2float_rd((double)n.origin[a] + (double)n.qlo[a][k] * step) : FLT_MAX;
+      f.plane[2 * a + 1][k] = used ? __double2float_ru((double)n.origin[a] + (double)n.qhi[a][k] * step) : -FLT_MAX;
+    }
+  }
+  for (int k = 0; k < 4; ++k)
+    f.child[k] = n.child[k], f.pad[k] = 0;
+  fat[i] = f;
+}
+
 // the model-level boxes are the reference's own (Model::transform's AABB, tested with its exact arithmetic): the caller brings them
 __global__ void k_refit_model_boxes(rtflat_model_node* dst, const rtflat_model_node* src, uint32_t n)
 {

@@ -43,6 +43,38 @@ __device__ __forceinline__ uint64_t laneMaskLe(float a, float b)
   asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
   return m;
 }
+// the seven 16-byte pieces of a FatNode a wave needs: near and far planes per axis (offsets chosen by the direction signs) and the
+// child references; issued together, one wait
+typedef int record4 __attribute__((ext_vector_type(4)));
+struct FatPieces
+{
+  record4 nx, fx, ny, fy, nz, fz, ch;
+};
+__device__ __forceinline__ FatPieces loadFat(const void* p, uint32_t offNX, uint32_t offFX, uint32_t offNY, uint32_t offFY, uint32_t offNZ, uint32_t offFZ)
+{
+  FatPieces f;
+  asm volatile("s_load_dwordx4 %0, %7, %8\n\t"
+               "s_load_dwordx4 %1, %7, %9\n\t"
+               "s_load_dwordx4 %2, %7, %10\n\t"
+               "s_load_dwordx4 %3, %7, %11\n\t"
+               "s_load_dwordx4 %4, %7, %12\n\t"
+               "s_load_dwordx4 %5, %7, %13\n\t"
+               "s_load_dwordx4 %6, %7, 0x60\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&s"(f.nx), "=&s"(f.fx), "=&s"(f.ny), "=&s"(f.fy), "=&s"(f.nz), "=&s"(f.fz), "=&s"(f.ch)
+               : "s"(p), "s"(offNX), "s"(offFX), "s"(offNY), "s"(offFY), "s"(offNZ), "s"(offFZ)
+               : "memory");
+  return f;
+}
+template <int K>
+__device__ __forceinline__ void fatSlab(const FatPieces& f, vec3 invD, vec3 noi, float& entry, float& exit)
+{
+  const float nx = rt::fma(__int_as_float(f.nx[K]), invD.x, noi.x), ny = rt::fma(__int_as_float(f.ny[K]), invD.y, noi.y), nz = rt::fma(__int_as_float(f.nz[K]), invD.z, noi.z);
+  const float fx = rt::fma(__int_as_float(f.fx[K]), invD.x, noi.x), fy = rt::fma(__int_as_float(f.fy[K]), invD.y, noi.y), fz = rt::fma(__int_as_float(f.fz[K]), invD.z, noi.z);
+  entry = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+  exit = fminf(fminf(fx, fy), fz);
+}
+
 constexpr uint32_t kPacketStack = 64; // entries of the wave stack: the host only picks this kernel when 3 * (BVH depth) fits
 
 // k_trace for COHERENT rays (MODE = PRIMARY: camera rays, generated here; SHADOW: any-hit toward every directional light
@@ -68,6 +100,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
   const rtflat_model_node* __restrict__ modelNodes = a.scene.modelNodes;
   const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(a.scene.nodes);
   const float4* __restrict__ tris4 = reinterpret_cast<const float4*>(a.scene.tris);
+  const FatNode* __restrict__ fat = a.scene.fat;
   const uint32_t numModelNodes = a.scene.numModelNodes;
 
   const bool sparse = a.list != nullptr;
@@ -163,6 +196,15 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
           nRays++;
         const vec3 invD = rtd::padInvDir(d);
         const vec3 oi = o * invD;
+        // Do the wave's rays agree on the sign of every direction component?  Then a child's near and far planes are the same
+        // for all of them and come straight out of the FatNode (see rt_kernel_common.h); otherwise this pass decodes the
+        // 64-byte records as before.
+        const uint64_t validMask = __ballot(valid);
+        const uint64_t sxm = __ballot(valid && invD.x < 0.0f), sym = __ballot(valid && invD.y < 0.0f), szm = __ballot(valid && invD.z < 0.0f);
+        const bool fatOk = fat != nullptr && (sxm == 0 || sxm == validMask) && (sym == 0 || sym == validMask) && (szm == 0 || szm == validMask);
+        const uint32_t offNX = sxm ? 16u : 0u, offFX = sxm ? 0u : 16u, offNY = sym ? 48u : 32u, offFY = sym ? 32u : 48u, offNZ = szm ? 80u : 64u,
+                       offFZ = szm ? 64u : 80u;
+        const vec3 noi{-oi.x, -oi.y, -oi.z};
         // AABB.h:49 divides by the direction: invD is that quotient unless it was clamped (axis-parallel rays)
         vec3 invRef = invD;
         if (fabsf(invD.x) == 1e18f || fabsf(invD.y) == 1e18f || fabsf(invD.z) == 1e18f)
@@ -264,19 +306,33 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
             {
               if (COUNT)
                 nNodeSteps++;
-              const record16 nd = loadRecord(nodes4 + (size_t)cur * 4);
-              if (COUNT)
-                nFetched++;
-              const float4 w0 = recordQuarter(nd, 0), w2 = recordQuarter(nd, 2), w3 = recordQuarter(nd, 3);
               if (COUNT && mine)
                 nNodes++;
               // every lane runs the box tests (a wave instruction costs the same for one lane as for 64; idle lanes carry a dummy
               // ray); the masks keep the lanes that are at this node.  Unused slots have inverted boxes.
               float en0, en1, en2, en3, ex0, ex1, ex2, ex3;
+              uint32_t r0, r1, r2, r3;
+              if (fatOk)
               {
+                const FatPieces f = loadFat(fat + cur, offNX, offFX, offNY, offFY, offNZ, offFZ);
+                if (COUNT)
+                  nFetched += 2; // 128 bytes
+                fatSlab<0>(f, invD, noi, en0, ex0);
+                fatSlab<1>(f, invD, noi, en1, ex1);
+                fatSlab<2>(f, invD, noi, en2, ex2);
+                fatSlab<3>(f, invD, noi, en3, ex3);
+                r0 = (uint32_t)f.ch[0], r1 = (uint32_t)f.ch[1], r2 = (uint32_t)f.ch[2], r3 = (uint32_t)f.ch[3];
+              }
+              else
+              {
+                const record16 nd = loadRecord(nodes4 + (size_t)cur * 4);
+                if (COUNT)
+                  nFetched++;
+                const float4 w0 = recordQuarter(nd, 0), w2 = recordQuarter(nd, 2), w3 = recordQuarter(nd, 3);
                 const rtd::WideNode wn = rtd::wideNodeSetup(w0, w2, w3, invD, oi);
                 rtd::wideSlabPair<0>(wn, en0, ex0, en1, ex1);
                 rtd::wideSlabPair<2>(wn, en2, ex2, en3, ex3);
+                r0 = (uint32_t)nd[4], r1 = (uint32_t)nd[5], r2 = (uint32_t)nd[6], r3 = (uint32_t)nd[7];
               }
               uint64_t m0 = laneMaskLe(en0, ex0) & mineMask, m1 = laneMaskLe(en1, ex1) & mineMask, m2 = laneMaskLe(en2, ex2) & mineMask,
                        m3 = laneMaskLe(en3, ex3) & mineMask;
@@ -288,7 +344,6 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
               uint32_t k1 = m1 ? (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(en1), (int)__builtin_ctzll(m1)) : 0xffffffffu;
               uint32_t k2 = m2 ? (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(en2), (int)__builtin_ctzll(m2)) : 0xffffffffu;
               uint32_t k3 = m3 ? (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(en3), (int)__builtin_ctzll(m3)) : 0xffffffffu;
-              uint32_t r0 = (uint32_t)nd[4], r1 = (uint32_t)nd[5], r2 = (uint32_t)nd[6], r3 = (uint32_t)nd[7];
               auto order = [](uint32_t& ka, uint32_t& ra, uint64_t& ma, uint32_t& kb, uint32_t& rb, uint64_t& mb) {
                 if (kb < ka)
                 {

@@ -159,6 +159,8 @@ struct rthip_ctx
   DevBuf<rtflat_model_node> modelNodes;
   DevBuf<rtflat_node> nodes;
   DevBuf<rtflat_tri> tris;
+  DevBuf<FatNode> fatNodes;      // the packet kernel's copy of `nodes` (k_fatten), rebuilt whenever the nodes change
+  bool useFat = true;            // (RTHIP_FAT=0: the packet kernel decodes the 64-byte records, the A/B baseline)
   DevBuf<Lights> lights;
   DevBuf<rthip_point_light> pointLights;
   Lights hostLights{};
@@ -338,6 +340,7 @@ DeviceScene devScene(const rthip_ctx* c)
   s.modelNodes = c->modelNodes.p;
   s.nodes = c->nodes.p;
   s.tris = c->tris.p;
+  s.fat = (c->useFat && c->fatNodes.n >= c->info.numNodes) ? c->fatNodes.p : nullptr;
   s.numModelNodes = c->info.numModelNodes;
   s.cullRel = c->info.cullRel;
   s.cullAbs = c->info.cullAbs;
@@ -522,6 +525,22 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
 
 // packet traversal needs its wave stack (64 entries, up to 3 pushes per level) to hold the deepest chain of the uploaded BVH
 bool packetsPossible(const rthip_ctx* c) { return 3u * c->info.maxDepthBlas + 2u <= kPacketStack; }
+
+// (re)builds the packet kernel's copy of the nodes; called wherever the node records change (upload, device build, refit)
+int fattenNodes(rthip_ctx* c)
+{
+  if (!c->useFat || !packetsPossible(c) || c->info.numNodes == 0)
+  {
+    c->fatNodes.release();
+    return 0;
+  }
+  if (int rc = c->fatNodes.ensure(c->info.numNodes))
+    return rc;
+  hipLaunchKernelGGL(k_fatten, dim3((c->info.numNodes + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->nodes.p, c->info.numNodes, c->fatNodes.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
 
 // the packet kernel (rt_packet.h) in place of k_trace<PRIMARY> / k_trace<SHADOW>: same arguments, same results
 template <int MODE>
@@ -1003,6 +1022,8 @@ static int createContext(rthip_ctx* c, int device)
     c->buildTraversalCost = (float)std::max(0.0, atof(t));
   if (const char* t = getenv("RTHIP_PLOC_RADIUS"))
     c->plocRadius = (uint32_t)std::max(1, std::min((int)kPlocMaxRadius, atoi(t)));
+  if (const char* t = getenv("RTHIP_FAT"))
+    c->useFat = atoi(t) != 0;
   if (const char* t = getenv("RTHIP_NO_SPLIT"))
     c->splitCalls = atoi(t) == 0;
   if (const char* t = getenv("RTHIP_PATHCAP_LOG2")) // tuning experiments only
@@ -1187,6 +1208,8 @@ int rthip_upload_scene(rthip_ctx* c, const rtflat_info* info, const rtflat_model
   c->spill.release(); // sized per scene in ensurePathBuffers
   c->alt.spill.release();
   c->materialsOn = false; // they described the previous scene's triangles
+  if (int rcFat = fattenNodes(c))
+    return rcFat;
   c->sceneEpoch++;
   c->haveScene = true;
   c->haveFrame = false;
@@ -1455,6 +1478,8 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
   c->spillCap = 3 * deepest + 2 > kStackLds ? 3 * deepest + 2 - kStackLds : 1u;
   c->spill.release(); // sized per scene in ensurePathBuffers
   c->alt.spill.release();
+  if (int rcFat = fattenNodes(c))
+    return rcFat;
   c->sceneEpoch++;
   c->haveScene = true;
   return 0;
@@ -1515,6 +1540,9 @@ int rthip_refit(rthip_ctx* c, const rtflat_model_node* modelNodes, const rtflat_
   if (msOut)
     HIPCHK(hipEventElapsedTime(msOut, c->evA, c->evB));
   c->sceneEpoch++; // (the traversal-mode measurement is taken again: the rays may behave differently now)
+  if (!outside)
+    if (int rcFat = fattenNodes(c))
+      return rcFat;
   if (outside)
   {
     c->haveScene = false; // the records have been overwritten; the caller flattens and uploads again
