@@ -216,7 +216,8 @@ struct rthip_ctx
   uint64_t refillKey = 0;        // what the current refillMode was measured for
   uint32_t sceneEpoch = 0;       // counts scene uploads
   float refillMs[4] = {0, 0, 0, 0}; // the calibration timings (low, high, packets, packets for camera rays only), for inspection
-  uint32_t packetBlocks = 8;     // resident blocks per CU of the packet kernel (RTHIP_PACKET_BLOCKS)
+  uint32_t packetBlocks = 4;     // resident blocks per CU of the packet kernel (RTHIP_PACKET_BLOCKS): 4 x 4 waves leave room for the other batch's
+                                 // list launches beside it (hf10m 157.6 -> 156.4 ms in two interleaved A/B runs; 6, 8, 12: no better)
   bool packetShadow = true;      // (RTHIP_PACKET_SHADOW=0: packets for camera rays only)
   bool closestLow = true;        // (RTHIP_CLOSEST_LOW=0: the first bounce rays use the high threshold)
   bool deepLow = true;           // bounce rays and the shadow rays of their hits are scattered whatever the camera rays were: low thresholds (RTHIP_DEEP_LOW=0: off; hf10m -2 %)

@@ -146,6 +146,14 @@ def test_config4_heightfield_8k_256spp_depth12(hf10m):
     c = r.counters()
     _identities(c, W, H, S, depth, len(spec.dir_lights))
     assert full.min() >= 0 and np.isfinite(full).all()
+    # all 256 sample passes of a 2x2 corner of the window against variant A (round 3): the whole samp-ordered accumulation
+    # of this configuration pinned to the brute-force oracle, not only its first pass
+    small = (win[0] + 30, win[1] + 30, win[0] + 32, win[1] + 32)
+    with heartbeat("variant A, 2x2 window, 256 spp"):
+        want = oracle.render(spec.oracle_camera(), W, H, S, max_depth=depth, window=small, workers=WORKERS)
+    x0, y0, x1, y1 = small
+    assert want["accumulator"][y0:y1, x0:x1].any()
+    assert np.array_equal(full[y0:y1, x0:x1].view(np.uint32), want["accumulator"][y0:y1, x0:x1].view(np.uint32))
     # the same frame on one slot, in calls of 100 passes: other batches, same bits
     r.set_option("pipelining", 0)
     r.begin_frame(spec.product_camera(), W, H, S)
