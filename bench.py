@@ -162,7 +162,9 @@ def roofline_block(workload, ktimes, wc, spp, ktimes_alone=None, scene_bytes=Non
     valu_ginst = (valu_insts / launch_s / 1e9) if valu_insts else None
     valu_frac = (valu_ginst / VALU_PEAK_GINST) if valu_ginst is not None else None
     cache_note = None
-    bound = "hbm"
+    # no counter data for this workload: the traversal families are VALU-bound wherever they were profiled, so
+    # that is the bound named (with no fraction: it needs the counters); the streaming kernels are HBM-bound
+    bound = "valu" if dominant in alg_flops else "hbm"
     if hbm_frac is not None and valu_frac is not None:
         bound = "hbm" if hbm_frac >= valu_frac else "valu"
     if scene_bytes is not None and scene_bytes < 32 * 2**20 and dominant in alg_flops:
@@ -538,6 +540,7 @@ def main():
     # Event pairs around every launch, resolved after the streams have drained: the frames below run exactly like the timed
     # ones (batches and frames overlapping), so a kernel's average duration here is what rocprofv3 reports for it.
     T = 3 if ms_per_step > 50 else 5
+    r.set_option("refillMode", _mode)  # the instrumented frames run in the traversal mode the timed ones ran in (no new measurement)
     r.set_option("kernelTiming", 1)
     for _ in range(T):
         r.begin_frame(cam, width, height, spp)
@@ -559,6 +562,7 @@ def main():
     r.render_passes(0, spp)
     wc = r.counters()
     r.set_option("countWork", 0)
+    r.set_option("refillMode", -1)
     roofline = roofline_block(args.workload, ktimes, wc, spp, ktimes_alone, 64 * (num_tris + num_nodes))
 
     # ---- the same scene through the DEVICE-built BVH (rthip_upload_scene_build): build time and frame time, untimed extra

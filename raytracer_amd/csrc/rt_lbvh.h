@@ -479,6 +479,50 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_emit(LbvhEmitArgs a)
   }
 }
 
+// ---- depth-first node order.  The collapse emits the wide tree level by level (breadth-first): a subtree's nodes end up
+// scattered over the whole array, and an incoherent ray's walk down a subtree touches a new memory region at every level.
+// The host builder writes depth-first pre-order, where a subtree is one contiguous run; these three kernels put the device's
+// tree into the same order (sizes bottom-up, offsets top-down, one launch per level each, then one permutation).
+__global__ __launch_bounds__(kBlock) void k_dfs_sizes(const rtflat_node* nodes, uint32_t levelBegin, uint32_t levelCount, uint32_t* sizes)
+{
+  const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= levelCount)
+    return;
+  const uint32_t i = levelBegin + k;
+  const rtflat_node& n = nodes[i];
+  uint32_t total = 1;
+  for (uint32_t c = 0; c < n.numChildren && c < 4; ++c)
+    if (!rtflat_is_leaf(n.child[c]) && n.child[c] != RTFLAT_INVALID)
+      total += sizes[n.child[c]]; // a child sits on a deeper level: written by an earlier launch
+  sizes[i] = total;
+}
+__global__ __launch_bounds__(kBlock) void k_dfs_offsets(const rtflat_node* nodes, uint32_t levelBegin, uint32_t levelCount, const uint32_t* sizes, uint32_t* newIndex)
+{
+  const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= levelCount)
+    return;
+  const uint32_t i = levelBegin + k;
+  const rtflat_node& n = nodes[i];
+  uint32_t next = newIndex[i] + 1; // (this node's own place was set by its parent's level, the root's by the host)
+  for (uint32_t c = 0; c < n.numChildren && c < 4; ++c)
+    if (!rtflat_is_leaf(n.child[c]) && n.child[c] != RTFLAT_INVALID)
+    {
+      newIndex[n.child[c]] = next;
+      next += sizes[n.child[c]];
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_dfs_permute(const rtflat_node* in, uint32_t first, uint32_t count, const uint32_t* newIndex, rtflat_node* out)
+{
+  const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= count)
+    return;
+  rtflat_node n = in[first + k];
+  for (uint32_t c = 0; c < 4; ++c)
+    if (n.child[c] != RTFLAT_INVALID && !rtflat_is_leaf(n.child[c]))
+      n.child[c] = newIndex[n.child[c]];
+  out[newIndex[first + k]] = n;
+}
+
 // triangle records into leaf order (order[i] = the model-order triangle that becomes record i)
 __global__ __launch_bounds__(kBlock) void k_lbvh_gather(const rtflat_tri* in, const uint32_t* ids, uint32_t n, rtflat_tri* out)
 {

@@ -200,6 +200,8 @@ struct rthip_ctx
   uint32_t traceBlocksTail = 768;
   uint32_t shadeTailBlocks = 128; // k_shade grid at depth >= 2, blocks per CU (RTHIP_SHADE_TAIL)
   int buildQuality = 0;          // device BVH build: 0 = Morton LBVH (default), 1 = PLOC over the Morton order (rthip_set_build_quality, RTHIP_BUILD_QUALITY)
+  bool buildNormalAware = true;   // device build: Morton bits dealt by cell extents that take the surfaces' orientation into account (RTHIP_BUILD_NORMALS=0: scene extents only)
+  bool buildDfsOrder = true;      // device build: nodes re-ordered depth-first after the collapse (RTHIP_BUILD_DFS=0: left breadth-first)
   float buildTraversalCost = 1.0f; // SAH cost of a node visit relative to a triangle test in the device build's leaf rule (RTHIP_BUILD_TCOST)
   uint32_t plocRadius = 16;      // neighbours searched on either side (RTHIP_PLOC_RADIUS)
   bool splitCalls = true;        // a call that fits one batch is still cut in two, one half per slot (RTHIP_NO_SPLIT=1: not)
@@ -817,6 +819,9 @@ int calibrateRefill(rthip_ctx* c)
   const uint32_t keepBegin = c->lastBatchBegin, keepCount = c->lastBatchCount, keepSamp = c->lastSamp;
   const bool keepRendered = c->renderedAny, keepTiming = c->kernelTiming;
   c->kernelTiming = false;
+  uint32_t keepLaunches[6];
+  for (int k = 0; k < 6; ++k)
+    keepLaunches[k] = c->kernelLaunches[k]; // (the measurement's launches are not the frame's: rthip_get_kernel_times must not count them)
   float ms[4] = {0, 0, 0, 0};
   int rc = 0;
   const bool packets = packetsPossible(c) && c->fusedPrimary && c->info.numNodes > 64;
@@ -853,6 +858,8 @@ int calibrateRefill(rthip_ctx* c)
       timedRun(&ms[mode]);
   }
   c->kernelTiming = keepTiming;
+  for (int k = 0; k < 6; ++k)
+    c->kernelLaunches[k] = keepLaunches[k];
   c->lastBatchBegin = keepBegin, c->lastBatchCount = keepCount, c->lastSamp = keepSamp, c->renderedAny = keepRendered;
   c->refillMode = 0;
   if (rc)
@@ -1019,6 +1026,10 @@ static int createContext(rthip_ctx* c, int device)
     c->shadeTailBlocks = (uint32_t)std::max(1, std::min(128, atoi(t)));
   if (const char* t = getenv("RTHIP_BUILD_QUALITY"))
     c->buildQuality = std::max(0, std::min(1, atoi(t)));
+  if (const char* t = getenv("RTHIP_BUILD_NORMALS"))
+    c->buildNormalAware = atoi(t) != 0;
+  if (const char* t = getenv("RTHIP_BUILD_DFS"))
+    c->buildDfsOrder = atoi(t) != 0;
   if (const char* t = getenv("RTHIP_BUILD_TCOST"))
     c->buildTraversalCost = (float)std::max(0.0, atof(t));
   if (const char* t = getenv("RTHIP_PLOC_RADIUS"))
@@ -1260,6 +1271,8 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
   DevBuf<LbvhNode> binary;
   DevBuf<uint8_t> done, sortTemp, scanTemp;
   DevBuf<uint4> frontier;
+  DevBuf<uint32_t> dfsSizes, dfsIndex;
+  DevBuf<rtflat_node> dfsNodes;
   constexpr uint32_t kLevels = (kMaxStack - 2) / 3; // deepest chain of 4-wide nodes the traversal stack can take
   constexpr uint32_t kSmallBinary = 2 + kLevels + 2, kSmallClusters = kSmallBinary + 1, kSmallWords = kSmallClusters + 1;
   if ((rc = c->modelNodes.ensure(info->numModelNodes)) || (rc = c->nodes.ensure(nodeCap)) || (rc = c->tris.ensure(numTris)) || (rc = c->lights.ensure(1)) ||
@@ -1309,20 +1322,49 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
   const float3 sceneLo = make_float3(info->sceneLo[0], info->sceneLo[1], info->sceneLo[2]);
   auto inv = [](float e) { return e > 0.0f ? 1.0f / e : 0.0f; };
   const float3 sceneInvExt = make_float3(inv(info->sceneHi[0] - info->sceneLo[0]), inv(info->sceneHi[1] - info->sceneLo[1]), inv(info->sceneHi[2] - info->sceneLo[2]));
-  // Morton bit layout: the code's 63 bits, most significant first, go to whichever axis is longest at that point (its extent is
-  // then halved), each axis taking at most 21.  A cube-shaped scene gets the usual x,y,z interleave; a flat one spends its leading
-  // bits where the triangles actually spread.
+  // Morton bit layout: the code's 63 bits, most significant first, go to whichever axis a cell is longest along at that
+  // point (its extent is then halved), each axis taking at most 21.  A cube-shaped cloud gets the usual x,y,z interleave.
+  // How long a cell is along an axis is not only the scene's extent: a surface that locally runs ACROSS an axis (a terrain's
+  // height) spans, inside a small cell, only its slope times the cell's width however tall the whole scene is -- spending a
+  // bit there splits a patch into "higher" and "lower" triangles whose boxes overlap in plan.  The triangles' normals say how
+  // the surfaces run: w_a = sqrt(1 - mean(n_a^2)) is large along axes the surfaces extend in; a cell's extent along a is taken
+  // as min(scene extent so far, w_a / w_max x its longest extent).  Terrain: x and z take their 21 bits each before the height
+  // gets one; a triangle soup (normals every way) keeps the round robin.
   MortonLayout layout;
   {
+    double n2[3] = {0, 0, 0};
+    const uint32_t stride = std::max(1u, numTris / (1u << 20));
+    uint64_t samples = 0;
+    for (uint32_t t = 0; t < numTris; t += stride, ++samples)
+      for (int a = 0; a < 3; ++a)
+        n2[a] += (double)trisModelOrder[t].n[a] * trisModelOrder[t].n[a];
+    double w[3], wmax = 0.0;
+    for (int a = 0; a < 3; ++a)
+    {
+      const double m = samples ? n2[a] / (double)samples : 1.0 / 3.0;
+      w[a] = std::sqrt(std::max(0.0, 1.0 - std::min(1.0, m)));
+      if (!(w[a] == w[a]))
+        w[a] = 0.8; // (NaN normals of degenerate records)
+      wmax = std::max(wmax, w[a]);
+    }
+    if (!c->buildNormalAware || wmax <= 0.0)
+      w[0] = w[1] = w[2] = wmax = 1.0;
     double ext[3] = {std::max(0.0, (double)info->sceneHi[0] - info->sceneLo[0]), std::max(0.0, (double)info->sceneHi[1] - info->sceneLo[1]),
                      std::max(0.0, (double)info->sceneHi[2] - info->sceneLo[2])};
     uint32_t taken[3] = {0, 0, 0};
     for (int bit = 62; bit >= 0; --bit)
     {
+      const double longest = std::max(ext[0], std::max(ext[1], ext[2]));
       int pick = -1;
+      double best = -1.0;
       for (int a = 0; a < 3; ++a)
-        if (taken[a] < 21 && (pick < 0 || ext[a] > ext[pick]))
-          pick = a;
+      {
+        if (taken[a] >= 21)
+          continue;
+        const double eff = std::min(ext[a], w[a] / wmax * longest);
+        if (eff > best)
+          best = eff, pick = a;
+      }
       layout.pos[pick][taken[pick]++] = (uint8_t)bit;
       ext[pick] *= 0.5;
     }
@@ -1436,9 +1478,34 @@ int rthip_upload_scene_build(rthip_ctx* c, rtflat_info* info, rtflat_model_node*
     HIPCHK(hipStreamSynchronize(c->stream));
     if (fin[1] || fin[2 + kLevels + 1]) // node array overflow, or nodes left beyond the deepest level the stack can take
       return RTHIP_E_LIMIT;
+    uint32_t modelLevels = 0;
     for (uint32_t level = 0; level <= kLevels; ++level)
       if (fin[2 + level])
-        deepest = std::max(deepest, level + 1);
+        modelLevels = level + 1;
+    deepest = std::max(deepest, modelLevels);
+    if (c->buildDfsOrder && fin[0] - root > 1)
+    {
+      // breadth-first (as emitted) -> depth-first pre-order, the host builder's layout: a subtree becomes one contiguous run
+      const uint32_t count = fin[0] - root;
+      if ((rc = dfsSizes.ensure(nodeCap)) || (rc = dfsIndex.ensure(nodeCap)) || (rc = dfsNodes.ensure(largest)))
+        return rc;
+      std::vector<uint32_t> levelBegin(modelLevels + 1, root);
+      for (uint32_t level = 0; level < modelLevels; ++level)
+        levelBegin[level + 1] = levelBegin[level] + fin[2 + level];
+      if (levelBegin[modelLevels] != fin[0] || count > dfsNodes.n)
+        return RTHIP_E_LIMIT;
+      for (uint32_t level = modelLevels; level-- > 0;)
+        hipLaunchKernelGGL(k_dfs_sizes, dim3((fin[2 + level] + kBlock - 1) / kBlock), block, 0, c->stream, c->nodes.p, levelBegin[level], fin[2 + level], dfsSizes.p);
+      HIPCHK(hipMemcpyAsync(dfsIndex.p + root, &root, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream)); // (&root is a local)
+      for (uint32_t level = 0; level < modelLevels; ++level)
+        hipLaunchKernelGGL(k_dfs_offsets, dim3((fin[2 + level] + kBlock - 1) / kBlock), block, 0, c->stream, c->nodes.p, levelBegin[level], fin[2 + level], dfsSizes.p,
+                           dfsIndex.p);
+      // (out[newIndex] with newIndex in [root, root + count): staged through a buffer of the model's size, then copied back)
+      hipLaunchKernelGGL(k_dfs_permute, dim3((count + kBlock - 1) / kBlock), block, 0, c->stream, c->nodes.p, root, count, dfsIndex.p, dfsNodes.p - root);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(c->nodes.p + root, dfsNodes.p, sizeof(rtflat_node) * count, hipMemcpyDeviceToDevice, c->stream));
+    }
     nodesUsed = fin[0];
     mn.blas = root;
   }
