@@ -280,6 +280,9 @@ def main():
     ap.add_argument("--dynamic", action="store_true", help="N>1: tiles from a shared cursor (dynamic rebalancing) instead of static round-robin")
     ap.add_argument("--tile-batch", type=int, default=16, help="--dynamic: tiles taken from the cursor at a time")
     ap.add_argument("--no-roofline", action="store_true", help="skip the extra instrumented frames (used under rocprofv3 --pmc)")
+    ap.add_argument("--family-times", action="store_true",
+                    help="with --no-roofline: still run the HIP-event timing frames (frames like the timed ones) and print each kernel family's "
+                         "average launch duration, so that a rocprofv3 --kernel-trace of THIS process can be set beside them")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the bounded CPU-baseline sample")
     ap.add_argument("--bvh", choices=("device", "host"), default="device",
                     help="which builder makes the triangle-level BVH of the timed frames: the device's (Morton LBVH + SAH leaves, "
@@ -530,7 +533,18 @@ def main():
         r.set_tiles(assignment[rank])
 
     if args.no_roofline:
-        print(json.dumps({"metric": "Mrays/s (primary+secondary)", "value": round(value, 2), "unit": "Mrays/s", "ms_per_step": round(ms_per_step, 4)}), flush=True)
+        fam = None
+        if args.family_times and world == 1:
+            T = 3 if ms_per_step > 50 else 5
+            r.set_option("refillMode", _mode)
+            r.set_option("kernelTiming", 1)
+            for _ in range(T):
+                r.begin_frame(cam, width, height, spp)
+                r.enqueue_passes(0, spp)
+            fam = {k: {"avg_launch_ms": round(ms / max(1, n), 5), "launches_per_frame": round(n / T, 2)} for k, (ms, n) in r.kernel_times().items() if n}
+            r.set_option("kernelTiming", 0)
+        print(json.dumps({"metric": "Mrays/s (primary+secondary)", "value": round(value, 2), "unit": "Mrays/s", "ms_per_step": round(ms_per_step, 4),
+                          "hip_event_family_times": fam}), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

@@ -15,12 +15,15 @@ for WL in hf10m soup1m; do
   bash tools/profile_pmc.sh $TAG $WL $STEPS > gpurun_out/${TAG}_${WL}_pmc.log 2>&1 || { echo "pmc $WL failed"; tail -5 gpurun_out/${TAG}_${WL}_pmc.log; exit 1; }
   D=gpurun_out/kt_${TAG}_${WL}
   KS=10; [ $WL = hf10m ] && KS=4
+  # --family-times: the process also measures every launch with HIP event pairs in three (five) more frames of the same kind and
+  # prints the per-family averages (bench_under_rocprof.json: hip_event_family_times) -- the figure bench.py's roofline block
+  # is built on, from the SAME process the CSV describes
   # --no-roofline: only frames that run like the timed ones (warm-up + timed steps, queued back to back on the two slots; the
   # traversal mode is pinned above, so no calibration batches either) reach the CSV: its average launch durations are the ones
   # bench.py's live avg_launch_ms measures with HIP events in its overlapped timing frames
-  timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --workload $WL --steps $KS --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/${TAG}_${WL}_kt.log 2>&1 || { echo "kernel trace $WL failed"; tail -5 gpurun_out/${TAG}_${WL}_kt.log; exit 1; }
+  timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --workload $WL --steps $KS --warmup 1 --no-cpu-baseline --no-roofline --family-times > gpurun_out/${TAG}_${WL}_kt.log 2>&1 || { echo "kernel trace $WL failed"; tail -5 gpurun_out/${TAG}_${WL}_kt.log; exit 1; }
   cp "$(find $D -name '*kernel_stats.csv' | head -1)" profiles/${TAG}_${WL}_kernel_stats.csv || exit 1
-  python3 tools/family_stats.py profiles/${TAG}_${WL}_kernel_stats.csv $((KS + 1)) > profiles/${TAG}_${WL}_family_stats.json || exit 1
+  python3 tools/family_stats.py profiles/${TAG}_${WL}_kernel_stats.csv $((KS + 1 + 3 + 2 * (KS > 4))) > profiles/${TAG}_${WL}_family_stats.json || exit 1
   grep "^{\"metric\"" gpurun_out/${TAG}_${WL}_kt.log | tail -n 1 > profiles/${TAG}_${WL}_bench_under_rocprof.json
   rm -rf $D gpurun_out/pmc_${TAG}_${WL}
 done
