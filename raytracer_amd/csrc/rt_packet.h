@@ -338,6 +338,38 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
                        m3 = laneMaskLe(en3, ex3) & mineMask;
               if (kClosest || pointPass)
                 m0 &= laneMaskLe(en0, cull), m1 &= laneMaskLe(en1, cull), m2 &= laneMaskLe(en2, cull), m3 &= laneMaskLe(en3, cull);
+              if (!kClosest)
+              {
+                // Any-hit rays need no order among the children (an OR over the triangles: CPUScene.cpp:107-121 visits both
+                // subtrees whatever happens), and on the scalar unit -- which this kernel keeps busier than the vector ALU since
+                // the float planes (profiles/r03_hf10m_pmc.json: 45.5 G scalar against 40.9 G vector instructions) -- the
+                // ordering is the largest item of a visit: four first-lane distance read-outs and a five-exchange network of
+                // branches and moves.  The children are taken in slot order: the lowest hit one next, the others on the stack
+                // (A/B of two library builds on one box: hf10m 155.7 -> 149.6 ms, bunny 1.42 -> 1.35 ms; round 2, when the vector
+                // ALU was the busier unit, measured no difference).
+                uint32_t next = RTFLAT_INVALID;
+                uint64_t nextMask = 0;
+                auto take = [&](uint32_t r, uint64_t m) {
+                  if (m)
+                  {
+                    if (next != RTFLAT_INVALID)
+                    {
+                      laneStackPush(stackRef, stackLo, stackHi, next, nextMask, sp);
+                      sp++;
+                    }
+                    next = r, nextMask = m;
+                  }
+                };
+                take(r3, m3), take(r2, m2), take(r1, m1), take(r0, m0);
+                if (next != RTFLAT_INVALID)
+                {
+                  cur = next;
+                  curMask = nextMask;
+                  continue;
+                }
+              }
+              else
+              {
               // children in the order of their entry distance along the first ray that hits each (any ray would do: the order
               // only decides how soon the culling distances shrink)
               uint32_t k0 = m0 ? (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(en0), (int)__builtin_ctzll(m0)) : 0xffffffffu;
@@ -379,6 +411,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
                 cur = r0;
                 curMask = m0;
                 continue;
+              }
               }
             }
             if (sp == 0)
