@@ -23,7 +23,8 @@ for WL in hf10m soup1m; do
   # bench.py's live avg_launch_ms measures with HIP events in its overlapped timing frames
   timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --workload $WL --steps $KS --warmup 1 --no-cpu-baseline --no-roofline --family-times > gpurun_out/${TAG}_${WL}_kt.log 2>&1 || { echo "kernel trace $WL failed"; tail -5 gpurun_out/${TAG}_${WL}_kt.log; exit 1; }
   cp "$(find $D -name '*kernel_stats.csv' | head -1)" profiles/${TAG}_${WL}_kernel_stats.csv || exit 1
-  python3 tools/family_stats.py profiles/${TAG}_${WL}_kernel_stats.csv $((KS + 1 + 3 + 2 * (KS > 4))) > profiles/${TAG}_${WL}_family_stats.json || exit 1
+  # last_frames: the trace's own durations of the launches of the 3 (5) event-timed frames alone
+  python3 tools/family_stats.py profiles/${TAG}_${WL}_kernel_stats.csv $((KS + 1 + 3 + 2 * (KS > 4))) "$(find $D -name '*kernel_trace.csv' | head -1)" $((3 + 2 * (KS > 4))) > profiles/${TAG}_${WL}_family_stats.json || exit 1
   grep "^{\"metric\"" gpurun_out/${TAG}_${WL}_kt.log | tail -n 1 > profiles/${TAG}_${WL}_bench_under_rocprof.json
   rm -rf $D gpurun_out/pmc_${TAG}_${WL}
 done
