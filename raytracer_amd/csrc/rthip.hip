@@ -210,6 +210,7 @@ struct rthip_ctx
   uint32_t tuneSteal = kFetchShards; // spans a wave may pull chunks from: its own first, then the others' (1 = its own only).  Off in round 1 (+4 % on the soup
                                      // then); with lists and the measured grid it is -5 % on hf10m at 4 spp and neutral on hf10m / soup1m (tools/ab_env.sh)
   uint32_t tuneRefill = kRefillThreshold, tuneLeaf = kLeafTrigger, tuneLeafHi = kLeafTriggerHi;
+  bool tuneLeafSet = false;      // RTHIP_TUNE named the leaf trigger: no per-mode choice on top of it
   uint32_t tuneRefillShadow = kRefillThreshold, tuneRefillPrimary = 32; // the low thresholds of shadow / dynamic primary launches (RTHIP_TUNE fields 8, 9)
   uint32_t tuneRefillHi = kRefillCoherent;                              // the high threshold (field 10)
   // Which refill thresholds the traversal launches use: low (incoherent rays) or high (coherent rays), see k_trace.  -1 in
@@ -489,7 +490,9 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   a.tmax = tmax;
   a.anyOut = c->anyOut.p;
   a.refillAt = (c->refillMode >= 1 && !(c->deepLow && (depth >= 2 || (MODE == CLOSEST && c->closestLow)))) ? c->tuneRefillHi : (isShadow(MODE) ? c->tuneRefillShadow : (MODE == PRIMARY ? c->tuneRefillPrimary : c->tuneRefill));
-  a.leafTrigger = c->tuneLeaf;
+  // scenes whose camera rays and first shadow rays go as packets (mode 2: coherent rays) let a few more lanes gather before a
+  // leaf step: hf10m 149.1 / 149.3 -> 147.7 / 147.5 ms (tools/ab_env.sh, interleaved); the soup (mode 0 / 3) loses 3.6 % with it
+  a.leafTrigger = (c->refillMode == 2 && !c->tuneLeafSet) ? std::max(c->tuneLeaf, 8u) : c->tuneLeaf;
   a.leafTriggerHi = c->tuneLeafHi;
   a.stealSpans = c->tuneSteal;
   a.foldFinal = foldFinal ? 1u : 0u;
@@ -1000,7 +1003,7 @@ static int createContext(rthip_ctx* c, int device)
     if (n >= 7 && lh >= 1 && lh <= 64)
       c->tuneLeafHi = lh;
     if (n >= 2 && r >= 1 && r <= 64 && l >= 1 && l <= 64)
-      c->tuneRefill = r, c->tuneLeaf = l;
+      c->tuneRefill = r, c->tuneLeaf = l, c->tuneLeafSet = true;
     if (n >= 3 && b >= 1 && b <= 8)
       c->tuneBlocks = b;
     if (n >= 4)
