@@ -1,6 +1,7 @@
 """Probe (not a test): what more launch batches in flight would buy -- R renderers (contexts) on one GPU, each with its own
 two slots, all rendering the same workload; reports the aggregate frame rate.
 usage: python tools/multi_ctx_probe.py <workload> <renderers> [frames]"""
+import os
 import sys
 import time
 
@@ -16,6 +17,11 @@ def main():
     spec = wl["spec"]()
     W, H, N, depth = wl["width"], wl["height"], wl["spp"], wl["max_depth"]
     rs = [spec.build_product(options=dict(maxDepth=depth)) for _ in range(R)]
+    share = int(os.environ.get("RT_SHARE", "1"))  # every renderer renders rank 0's tiles of a `share`-GPU run
+    if share > 1:
+        from raytracer_amd import dist as rdist
+        for r in rs:
+            r.set_tiles(rdist.assign_tiles(W, H, share)[0])
     cam = spec.product_camera()
     for rep in range(3):
         t = time.perf_counter()
