@@ -597,7 +597,7 @@ def main():
             r2.begin_frame(cam, width, height, spp)
             r2.enqueue_passes(0, spp)
         r2.synchronize()
-        reps = 3 if ms_per_step > 50 else 10
+        reps = max(3, args.steps)  # as many frames queued back to back as the timed region had: a shorter run carries more of the pipeline's ramp and drain per frame
         t1 = time.perf_counter()
         for _ in range(reps):
             r2.begin_frame(cam, width, height, spp)

@@ -770,7 +770,7 @@ BatchPlan planBatches(const rthip_ctx* c, uint32_t count, const FrameGeom& g, ui
 // the local tile list, the sample passes one call would bring, about 16M paths each, as far as the path buffers allow), so that
 // every candidate is timed with another batch beside it as in a pipelined frame (round 2 timed one batch alone, which is blind
 // to what overlap changes: the grid a setting leaves to the other batch, mode 3's win at few samples per pixel).  A frame that
-// is not pipelined (one slot) is measured on one slot.  Every candidate runs once untimed first (caches warm), nothing reaches
+// is not pipelined (one slot) is measured on one slot.  The first candidate runs once untimed (caches warm; its duration sets how many sample pairs a measurement queues), nothing reaches
 // the accumulator, the AOVs or the counters.  Called by rthip_begin when the scene, its shading switches or the frame's shape
 // have changed since the last measurement: a few batches and one host synchronisation, then frames queue without waiting.
 uint64_t calibrationKey(const rthip_ctx* c)
@@ -811,14 +811,18 @@ int calibrateRefill(rthip_ctx* c)
   uint64_t slotCap = std::min<uint64_t>(std::min<uint64_t>(c->rayO.n, c->listA.n), std::min<uint64_t>(c->hit.n, c->pathCap));
   if (both)
     slotCap = std::min<uint64_t>(slotCap, std::min<uint64_t>(std::min<uint64_t>(c->alt.rayO.n, c->alt.listA.n), c->alt.hit.n));
-  const uint32_t tiles = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(wantTiles, c->geom.numLocalTiles / (both ? 2u : 1u)), slotCap / ((uint64_t)perTile * samples));
+  // a sample batch is no wider than the batches the frame itself will be cut into; a frame that is ONE batch (the 1M soup: two
+  // whole frames in flight on the two slots) is sampled whole on both slots -- half-frame batches have other tails than it has
+  const BatchPlan plan = planBatches(c, c->geom.numSamples, c->geom, 0, c->framePipelined);
+  const uint32_t tiles = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(wantTiles, plan.tiles), slotCap / ((uint64_t)perTile * samples));
   if (tiles == 0)
   {
     c->refillMode = 0;
     return 0;
   }
-  const uint32_t span = both ? 2 * tiles : tiles;
-  const uint32_t first = (c->geom.numLocalTiles - span) / 2;
+  const bool sideBySide = both && 2ull * tiles <= c->geom.numLocalTiles; // else both slots trace the same tiles
+  const uint32_t span = sideBySide ? 2 * tiles : tiles;
+  const uint32_t first = (c->geom.numLocalTiles - span) / 2, second = sideBySide ? first + tiles : first;
   const uint32_t keepBegin = c->lastBatchBegin, keepCount = c->lastBatchCount, keepSamp = c->lastSamp;
   const bool keepRendered = c->renderedAny, keepTiming = c->kernelTiming;
   c->kernelTiming = false;
@@ -829,19 +833,26 @@ int calibrateRefill(rthip_ctx* c)
   int rc = 0;
   const bool packets = packetsPossible(c) && c->fusedPrimary && c->info.numNodes > 64;
   const int numModes = packets ? 4 : 2;
-  auto timedRun = [&](float* msOut) {
+  // `reps` sample pairs queued back to back between the two events: a small frame (the 1M soup: 2M paths) is over in a few
+  // milliseconds, most of them ramp and tail, which frames queued one behind the other overlap with their neighbours -- one pair
+  // timed alone favoured whatever shortens a lone frame's critical path (it picked mode 3 for the soup, 4.6 % slower in a run of frames)
+  auto timedRun = [&](float* msOut, uint32_t reps) {
     rc = (int)hipEventRecord(c->evA, c->stream);
     if (!rc && both)
       rc = (int)hipStreamWaitEvent(c->alt.stream, c->evA, 0);
-    if (!rc)
+    for (uint32_t rep = 0; rep < reps && !rc; ++rep)
+    {
       rc = renderBatch(c, 0, samples, first, tiles, false, nullptr, true);
+      if (!rc && both)
+      {
+        swapSlot(c);
+        rc = renderBatch(c, 0, samples, second, tiles, false, nullptr, true);
+        swapSlot(c);
+      }
+    }
     if (!rc && both)
     {
-      swapSlot(c);
-      rc = renderBatch(c, 0, samples, first + tiles, tiles, false, nullptr, true);
-      if (!rc)
-        rc = (int)hipEventRecord(c->evDone, c->stream);
-      swapSlot(c);
+      rc = (int)hipEventRecord(c->alt.evDone, c->alt.stream);
       if (!rc)
         rc = (int)hipStreamWaitEvent(c->stream, c->alt.evDone, 0);
     }
@@ -850,15 +861,24 @@ int calibrateRefill(rthip_ctx* c)
     if (!rc)
       rc = (int)hipEventSynchronize(c->evB);
     if (!rc && msOut)
+    {
       rc = (int)hipEventElapsedTime(msOut, c->evA, c->evB);
+      *msOut /= (float)reps;
+    }
   };
+  uint32_t reps = 1;
   for (int mode = 0; mode < numModes && !rc; ++mode)
   {
     c->refillMode = mode;
     if (mode == 0)
-      timedRun(nullptr); // warm the caches once
+    {
+      float warm = 0.0f;
+      timedRun(&warm, 1); // warms the caches, and says how many pairs make a measurement of about 16 ms
+      if (!rc && warm > 0.0f)
+        reps = (uint32_t)std::max(1.0f, std::min(8.0f, 16.0f / warm));
+    }
     if (!rc)
-      timedRun(&ms[mode]);
+      timedRun(&ms[mode], reps);
   }
   c->kernelTiming = keepTiming;
   for (int k = 0; k < 6; ++k)
