@@ -51,6 +51,7 @@ struct ShadeArgs
   uint32_t numSlots, depth, maxDepth, sampBegin;
   uint32_t finalFold;      // 1: only fold the pending lights and finish every path (depth == maxDepth)
   uint32_t primaryInRegs;  // 1: depth-0 rays were never stored; recompute them from (pixel, sample)
+  uint32_t maskSplit;      // > 0: this depth's shadow launch wrote mask[] as one byte per light, for this many lights (k_trace<SHADOW>, splitLg)
   uint32_t aovDepths;
   uint32_t* aovTri;        // [S][aovDepths][P]
   uint8_t* aovShadow;      // [S][aovDepths][P]
@@ -133,7 +134,9 @@ __global__ __launch_bounds__(kBlock, 8) void k_shade(ShadeArgs a)
           radiance = vec3{s0.x, s0.y, s0.z};
           // lights of the previous hit, whose position is this ray's origin (CPUScene.cpp:31-49)
           const bool shadowed = a.lights->numDir || (a.scene.pointShadows && a.lights->numPoint);
-          const uint32_t occl = shadowed ? a.pb.mask[p] : 0u;
+          uint32_t occl = shadowed ? a.pb.mask[p] : 0u;
+          if (a.maskSplit) // this depth's shadow launch wrote one byte per light (k_trace<SHADOW>, splitLg)
+            occl = ((occl & 1u) | ((occl >> 7) & 2u) | ((occl >> 14) & 4u) | ((occl >> 21) & 8u)) & ((1u << a.maskSplit) - 1u);
           vec3 albedoPrev = referenceAlbedo();
           if (MAT)
           {

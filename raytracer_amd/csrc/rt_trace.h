@@ -22,6 +22,7 @@ struct TraceArgs
   uint32_t leafTrigger;      // lanes waiting on a leaf that trigger a leaf step once their number has stopped growing ...
   uint32_t leafTriggerHi;    // ... or at once when this many wait
   uint32_t stealSpans;       // spans a wave may pull chunks from: its own first, then its neighbours'
+  uint32_t splitLg;          // SHADOW over a list: log2 of the number of directional lights when every (path, light) pair is an item of its own (see k_trace); 0 = a lane tests a path's lights one after the other
   uint32_t* fetch;           // dynamic mode: kFetchShards counters, kFetchStride words apart, zeroed before the launch
   uint32_t depth;            // live[] value this launch serves (dense mode filter)
   uint32_t* spill;           // [spillCap][gridLanes]
@@ -59,7 +60,11 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 4)) void k_tra
   //  dynamic mode: a persistent grid; the items are split into kFetchShards contiguous spans (one per XCD label, so that
   //    an XCD's L2 keeps seeing the same image region) and a wave pulls chunkLen items at a time from its span's counter.
   const bool sparse = a.list != nullptr;
-  const uint32_t total = sparse ? *a.listCount : a.numSlots;
+  // SHADOW with splitLg: the scattered shadow rays of the deeper depths are few, and a launch lasts as long as its longest lane.
+  // One item per (path, light) -- the light in the top two bits of the wave's list entry -- makes twice (four times) as many
+  // items of half (a quarter) the length; each writes its own byte of mask[slot], which k_shade folds back into bits.
+  const uint32_t splitLg = MODE == SHADOW ? a.splitLg : 0u;
+  const uint32_t total = sparse ? (*a.listCount << splitLg) : a.numSlots;
   constexpr bool dynamic = MODE != PRIMARY_GROUP;
   const uint32_t wid = xcdRemap(blockIdx.x, gridDim.x) * kWavesPerBlock + wv;
   uint32_t runNext = dynamic ? 0u : min(total, wid * a.runLen);
@@ -113,6 +118,7 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 4)) void k_tra
   uint32_t postponed = 0xfffffffeu; // a leaf reference parked while the lane keeps walking inner nodes (kNone = none)
   bool needPop = false;          // the lane needs a new `cur` from its stack / the model tree
   uint32_t lightIdx = 0;         // SHADOW: which light this lane is testing (directional lights first, then -- SHADOW_PT -- point lights)
+  uint32_t lightEnd = 0;         // SHADOW: one past the last light this lane tests for its path
   uint32_t occluded = 0;         // SHADOW: result bits
   float prevNx = 0.0f;           // SHADOW: rayO.w, the face normal x of the hit the shadow rays leave from
   vec3 hitPos{0, 0, 0}, hitN{0, 0, 0}; // SHADOW_PT: that hit's position and face normal (a point light's ray starts off the surface)
@@ -168,6 +174,8 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 4)) void k_tra
       a.pb.s0[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
       a.pb.live[slot] = kDead;
     }
+    else if (splitLg)
+      reinterpret_cast<uint8_t*>(a.pb.mask)[(size_t)slot * 4 + (lightEnd - 1u)] = (uint8_t)((occluded >> (lightEnd - 1u)) & 1u);
     else
       a.pb.mask[slot] = occluded;
   };
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 4)) void k_tra
           if (sparse)
           {
             if (isLive)
-              s = a.list[item];
+              s = splitLg ? (a.list[item >> splitLg] | ((item & ((1u << splitLg) - 1u)) << 30)) : a.list[item];
           }
           else
             isLive = isLive && (a.pb.live[item] == (uint8_t)a.depth);
@@ -312,13 +320,20 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 4)) void k_tra
         if (take)
         {
           slot = list[listNext + r];
+          uint32_t firstLight = 0;
+          if (splitLg)
+          {
+            firstLight = slot >> 30;
+            slot &= 0x3fffffffu;
+          }
           const float4 ro = a.pb.rayO[slot];
           o = vec3{ro.x, ro.y, ro.z};
           best = FLT_MAX;
           cull = FLT_MAX;
           if (isShadow(MODE))
           {
-            lightIdx = 0;
+            lightIdx = firstLight;
+            lightEnd = splitLg ? firstLight + 1u : numShadowLights;
             occluded = 0;
             prevNx = ro.w;
             if (MODE == SHADOW_PT)
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 4)) void k_tra
               hitPos = o;
               hitN = vec3{ro.w, a.pb.s0[slot].w, a.pb.nz[slot]};
             }
-            aimAtLight(0);
+            aimAtLight(lightIdx);
           }
           else
           {
@@ -423,7 +438,7 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 4)) void k_tra
         {
           // not occluded for this light; the next light restarts the walk
           lightIdx++;
-          if (lightIdx < numShadowLights)
+          if (lightIdx < lightEnd)
           {
             aimAtLight(lightIdx);
             mk = 0;
@@ -514,7 +529,7 @@ __global__ __launch_bounds__(kBlock, (MODE == PRIMARY_GROUP ? 5 : 4)) void k_tra
             {
               occluded |= 1u << lightIdx;
               lightIdx++;
-              if (lightIdx < numShadowLights)
+              if (lightIdx < lightEnd)
               {
                 aimAtLight(lightIdx);
                 mk = 0;

@@ -222,6 +222,7 @@ struct rthip_ctx
   uint32_t packetBlocks = 4;     // resident blocks per CU of the packet kernel (RTHIP_PACKET_BLOCKS): 4 x 4 waves leave room for the other batch's
                                  // list launches beside it (hf10m 157.6 -> 156.4 ms in two interleaved A/B runs; 6, 8, 12: no better)
   bool packetShadow = true;      // (RTHIP_PACKET_SHADOW=0: packets for camera rays only)
+  bool splitLights = true;       // (RTHIP_SPLIT_LIGHTS=0: deep shadow launches test a path's lights in one lane, one after the other)
   bool closestLow = true;        // (RTHIP_CLOSEST_LOW=0: the first bounce rays use the high threshold)
   bool deepLow = true;           // bounce rays and the shadow rays of their hits are scattered whatever the camera rays were: low thresholds (RTHIP_DEEP_LOW=0: off; hf10m -2 %)
   uint32_t calibLog2 = 24;       // paths in the calibration sample (RTHIP_CALIB_LOG2): fewer, and launches are tail-bound, which hides the difference
@@ -466,6 +467,15 @@ int ensurePathBuffers(rthip_ctx* c, size_t numSlots)
   return 0;
 }
 
+// Deep shadow launches (depth >= 2: scattered rays, few of them) make one item of every (path, light) pair when the scene has two
+// or four directional lights: log2 of that number, 0 = a lane tests its path's lights one after the other (k_trace, splitLg)
+uint32_t shadowSplitLg(const rthip_ctx* c, uint32_t depth)
+{
+  if (!c->splitLights || depth < 2)
+    return 0;
+  return c->hostLights.numDir == 2 ? 1u : (c->hostLights.numDir == 4 ? 2u : 0u);
+}
+
 // list == nullptr: dense launch over all numSlots slots; otherwise a launch over the device-side slot list of `depth`,
 // whose length (counters->listCount[depth]) only the device knows: the whole persistent grid is launched and sizes its
 // chunks from that length
@@ -495,6 +505,7 @@ int launchTrace(rthip_ctx* c, uint32_t numSlots, uint32_t depth, uint32_t sampBe
   a.leafTrigger = (c->refillMode == 2 && !c->tuneLeafSet) ? std::max(c->tuneLeaf, 8u) : c->tuneLeaf;
   a.leafTriggerHi = c->tuneLeafHi;
   a.stealSpans = c->tuneSteal;
+  a.splitLg = (MODE == SHADOW && list && !foldFinal) ? shadowSplitLg(c, depth) : 0u;
   a.foldFinal = foldFinal ? 1u : 0u;
   a.aovDepths = c->aovDepths;
   a.aovShadow = c->aovShadow.p;
@@ -697,6 +708,8 @@ int renderBatch(rthip_ctx* c, uint32_t sampBegin, uint32_t count, uint32_t tileB
       HIPCHK(hipStreamWaitEvent(c->stream, c->evJoin, 0));
     sa.depth = d;
     sa.finalFold = last ? 1u : 0u;
+    // (the shadow launch of this depth, above: per-lane over the list, not the last depth's fold, no point-light shadow rays)
+    sa.maskSplit = (d >= 2 && !last && haveDirLights && !shadowPoints && shadowSplitLg(c, d)) ? c->hostLights.numDir : 0u;
     sa.list = list;
     sa.listNext = last ? nullptr : listNext;
     {
@@ -1077,6 +1090,8 @@ static int createContext(rthip_ctx* c, int device)
     c->deepLow = atoi(t) != 0;
   if (const char* t = getenv("RTHIP_CALIB_LOG2"))
     c->calibLog2 = (uint32_t)std::max(16, std::min(27, atoi(t)));
+  if (const char* t = getenv("RTHIP_SPLIT_LIGHTS"))
+    c->splitLights = atoi(t) != 0;
   if (const char* t = getenv("RTHIP_REFILL_MODE")) // 0 / 1: fixed low / high refill thresholds instead of the measured choice
     c->refillWanted = std::max(0, std::min(3, atoi(t)));
   if (const char* t = getenv("RTHIP_GROUP_LG"))
