@@ -115,6 +115,12 @@ LIGHT_SETUPS = {
                               (np.array([0.05, 0.99, 0.13], np.float32), (0.3, 0.3, 0.9))],
                   point_lights=[((1.6, 0.4, 0.9), (1, 0.5, 0.25), 3.0), ((0, 2.5, 0), (0.2, 0.9, 0.4), 4.0)]),
     "no_lights": dict(dir_lights=[], point_lights=[]),
+    # two and four directional lights: from depth 2 on the shadow launches take one item per (path, light) and write one byte
+    # of mask[] per light (k_trace<SHADOW>, splitLg = 1 and 2), which k_shade folds back into the occlusion bits
+    "two_dir": dict(dir_lights=[(scenes.main_light_dir(), (1, 1, 1)), (np.array([0.6, -0.64, 0.48], np.float32), (0.5, 0.25, 0.125))], point_lights=[]),
+    "four_dir": dict(dir_lights=[(scenes.main_light_dir(), (1, 1, 1)), (np.array([0.6, -0.64, 0.48], np.float32), (0.5, 0.25, 0.125)),
+                                 (np.array([0.05, 0.99, 0.13], np.float32), (0.3, 0.3, 0.9)), (np.array([-0.7, -0.5, -0.5], np.float32), (0.2, 0.7, 0.4))],
+                     point_lights=[((1.6, 0.4, 0.9), (1, 0.5, 0.25), 3.0)]),
 }
 
 
