@@ -9,7 +9,9 @@
 //   binary tree, one of
 //    quality 0 (LBVH):  k_lbvh_topology  binary radix tree over the sorted codes (Karras 2012), one thread per inner node
 //                       k_lbvh_refit     boxes bottom-up, one launch per tree level (a node is finished once both children were
-//                                        finished by an EARLIER launch: kernel boundaries order the box writes)
+//                                        finished by an EARLIER launch: kernel boundaries order the box writes); on the way a node
+//                                        re-pairs its grandchildren when that gives its children smaller boxes (tree rotations;
+//                                        the refit runs twice for two rounds of them)
 //    quality 1 (PLOC, Meister & Bittner 2018: parallel locally-ordered clustering; round 3, the default):
 //                       k_ploc_nearest   every cluster of the Morton-ordered cluster array finds, among its `radius` neighbours
 //                                        on either side, the one whose union with it has the smallest surface area
@@ -166,8 +168,18 @@ __device__ __forceinline__ LbvhBox lbvhUnion(const LbvhBox& a, const LbvhBox& b)
 // One level of the bottom-up refit.  done[i] = the pass (>= 1) in which inner node i got its box; a child counts as finished
 // only if an EARLIER pass finished it, so every box this launch reads was written before the launch began.
 // ids: sorted position -> triangle (leaf boxes are the triangles' own)
-__global__ __launch_bounds__(kBlock) void k_lbvh_refit(const LbvhNode* nodes, uint32_t numInner, const LbvhBox* primBoxes, const uint32_t* ids, LbvhBox* innerBoxes,
-                                                       uint8_t* done, uint32_t pass)
+__device__ __forceinline__ float lbvhHalfArea(const LbvhBox& b)
+{
+  const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+
+// rotate != 0: before a node takes its box, its (up to four) grandchildren are re-paired if another pairing gives the two children
+// smaller boxes (sum of their surface areas; a leaf child may trade places with a grandchild).  The node owns its children --
+// both were finished by earlier launches and have no other parent -- so rewriting them races with nothing; its own box is the
+// union of the same triangles either way.  (Bottom-up tree rotations, Kensler 2008, done in the refit's own passes.)
+__global__ __launch_bounds__(kBlock) void k_lbvh_refit(LbvhNode* nodes, uint32_t numInner, const LbvhBox* primBoxes, const uint32_t* ids, LbvhBox* innerBoxes,
+                                                       uint8_t* done, uint32_t pass, uint32_t rotate)
 {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= numInner || done[i])
@@ -179,18 +191,72 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_refit(const LbvhNode* nodes, ui
     return;
   if (!rLeaf && !(done[ri] && done[ri] < pass))
     return;
-  const LbvhBox a = lLeaf ? primBoxes[ids[li]] : innerBoxes[li];
-  const LbvhBox b = rLeaf ? primBoxes[ids[ri]] : innerBoxes[ri];
+  auto boxOf = [&](uint32_t ref) { return (ref & 0x80000000u) ? primBoxes[ids[ref & 0x7fffffffu]] : innerBoxes[ref]; };
+  auto countOf = [&](uint32_t ref) { return (ref & 0x80000000u) ? 1u : nodes[ref].count; };
+  LbvhBox a = lLeaf ? primBoxes[ids[li]] : innerBoxes[li];
+  LbvhBox b = rLeaf ? primBoxes[ids[ri]] : innerBoxes[ri];
+  if (rotate && !(lLeaf && rLeaf))
+  {
+    if (!lLeaf && !rLeaf)
+    {
+      // grandchildren (l1 l2 | r1 r2): the other two pairings
+      const LbvhNode L = nodes[li], R = nodes[ri];
+      const LbvhBox l1 = boxOf(L.left), l2 = boxOf(L.right), r1 = boxOf(R.left), r2 = boxOf(R.right);
+      const LbvhBox p11 = lbvhUnion(l1, r1), p22 = lbvhUnion(l2, r2), p12 = lbvhUnion(l1, r2), p21 = lbvhUnion(l2, r1);
+      const float keep = lbvhHalfArea(a) + lbvhHalfArea(b);
+      const float alt1 = lbvhHalfArea(p11) + lbvhHalfArea(p22), alt2 = lbvhHalfArea(p12) + lbvhHalfArea(p21);
+      if (alt1 < keep && alt1 <= alt2)
+      {
+        nodes[li] = LbvhNode{L.left, R.left, countOf(L.left) + countOf(R.left), 0u};
+        nodes[ri] = LbvhNode{L.right, R.right, countOf(L.right) + countOf(R.right), 0u};
+        innerBoxes[li] = a = p11, innerBoxes[ri] = b = p22;
+      }
+      else if (alt2 < keep)
+      {
+        nodes[li] = LbvhNode{L.left, R.right, countOf(L.left) + countOf(R.right), 0u};
+        nodes[ri] = LbvhNode{L.right, R.left, countOf(L.right) + countOf(R.left), 0u};
+        innerBoxes[li] = a = p12, innerBoxes[ri] = b = p21;
+      }
+    }
+    else
+    {
+      // one child is a triangle: it may trade places with one of the other child's children
+      const uint32_t inner = lLeaf ? ri : li, leafRef = lLeaf ? nd.left : nd.right;
+      const LbvhNode I = nodes[inner];
+      const LbvhBox t = lLeaf ? a : b, inBox = lLeaf ? b : a;
+      const LbvhBox c1 = boxOf(I.left), c2 = boxOf(I.right);
+      const float keep = lbvhHalfArea(inBox); // (the triangle's own box counts the same in every arrangement: one of the three is always alone)
+      const LbvhBox w1 = lbvhUnion(t, c2), w2 = lbvhUnion(c1, t); // I.left alone / I.right alone
+      const float alt1 = lbvhHalfArea(w1) + lbvhHalfArea(c1) - lbvhHalfArea(t), alt2 = lbvhHalfArea(w2) + lbvhHalfArea(c2) - lbvhHalfArea(t);
+      uint32_t alone = 0xffffffffu;
+      if (alt1 < keep && alt1 <= alt2)
+      {
+        alone = I.left;
+        nodes[inner] = LbvhNode{leafRef, I.right, 1u + countOf(I.right), 0u};
+        innerBoxes[inner] = w1;
+      }
+      else if (alt2 < keep)
+      {
+        alone = I.right;
+        nodes[inner] = LbvhNode{I.left, leafRef, countOf(I.left) + 1u, 0u};
+        innerBoxes[inner] = w2;
+      }
+      if (alone != 0xffffffffu)
+      {
+        // the node's children: the grandchild that now stands alone, and the rebuilt inner node
+        const LbvhBox aloneBox = boxOf(alone), rebuilt = innerBoxes[inner];
+        nodes[i] = lLeaf ? LbvhNode{alone, inner, nd.count, 0u} : LbvhNode{inner, alone, nd.count, 0u};
+        a = lLeaf ? aloneBox : rebuilt;
+        b = lLeaf ? rebuilt : aloneBox;
+        // (an inner `alone` was finished by an earlier pass, like `inner`: the done[] bookkeeping stands)
+      }
+    }
+  }
   innerBoxes[i] = lbvhUnion(a, b);
   done[i] = (uint8_t)pass;
 }
 
 // ------------------------------------------------------------------------------------------------ PLOC
-__device__ __forceinline__ float lbvhHalfArea(const LbvhBox& b)
-{
-  const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
-  return dx * dy + dy * dz + dz * dx;
-}
 constexpr uint32_t kPlocMaxRadius = 32;
 
 // nearest[i] = the cluster within `radius` positions of i whose union with cluster i has the smallest surface area (the
