@@ -191,6 +191,31 @@ RTD int triangleTest(vec3 p0, vec3 e0, vec3 e1, vec3 o, vec3 d, float tmin, floa
   return 1;
 }
 
+// The same test with s1 = cross(d, e1) and fraction = 1 / dot(s1, e0) brought in: for the shadow rays toward one directional light
+// they depend on the triangle alone and are computed once per scene (k_shadow_operands) by these very operations, so every
+// value below has the bits triangleTest gives it.
+RTD int triangleTestWith(vec3 p0, vec3 e0, vec3 e1, vec3 o, vec3 d, vec3 s1, float fraction, float tmin, float tmax, float& tOut)
+{
+  const vec3 s = o - p0;
+  const vec3 s2 = rt::cross(s, e0);
+  const float t = rt::dot(s2, e1) * fraction;
+  const float b1 = rt::dot(s1, s) * fraction;
+  const float b2 = rt::dot(s2, d) * fraction;
+  const float b3 = 1.0f - b1 - b2;
+  if (b3 < 0 || b3 > 1)
+    return 0;
+  if (b1 < 0 || b1 > 1)
+    return 0;
+  if (b2 < 0 || b2 > 1)
+    return 0;
+  if (t < tmin || t > tmax)
+    return 0;
+  tOut = t;
+  if (!(fabsf(t) <= FLT_MAX && fabsf(b1) <= FLT_MAX && fabsf(b2) <= FLT_MAX))
+    return 2;
+  return 1;
+}
+
 // ---- materials (include/rtflat.h: rtflat_shade / rtflat_material)
 // The texture coordinates the reference's intersector attaches to a hit (CPUScene.cpp:217-219): the triangle test's own
 // barycentrics, recomputed here for the winning record from the same operands in the same order, so the same bits.

@@ -66,6 +66,11 @@ struct DeviceScene
   const rtflat_node* nodes;
   const FatNode* fat;      // nullptr: not built (the packet kernel then decodes the 64-byte records)
   const rtflat_tri* tris;
+  // the packet kernel's per-light triangle operands (k_shadow_operands; nullptr: not built): for directional light l and record
+  // r, entry [l * numTris + r] = (cross(d_l, e1), 1 / dot(cross(d_l, e1), e0)) -- the part of the reference's triangle test
+  // (CPUScene.cpp:163,166) that is the same for every shadow ray toward that light
+  const float4* shadowOperands;
+  uint32_t numTris;
   uint32_t numModelNodes;
   float cullRel, cullAbs;
   // shading inputs (rthip_upload_materials); materialsOn == 0: the reference's hard-coded albedo

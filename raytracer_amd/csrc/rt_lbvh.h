@@ -691,6 +691,24 @@ __global__ __launch_bounds__(kBlock) void k_fatten(const rtflat_node* nodes, uin
   fat[i] = f;
 }
 
+// the packet kernel's per-light triangle operands (DeviceScene::shadowOperands): one thread per record, every directional light
+__global__ __launch_bounds__(kBlock) void k_shadow_operands(const rtflat_tri* tris, uint32_t numTris, const Lights* lights, uint32_t numLights, float4* out)
+{
+  const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= numTris)
+    return;
+  const rtflat_tri t = tris[r];
+  const vec3 e0{t.e0[0], t.e0[1], t.e0[2]}, e1{t.e1[0], t.e1[1], t.e1[2]};
+  for (uint32_t l = 0; l < numLights; ++l)
+  {
+    const rthip_dir_light& L = lights->dir[l];
+    const vec3 d{-L.direction[0], -L.direction[1], -L.direction[2]}; // as the shadow kernels aim: Ray(position, -d.direction), CPUScene.cpp:34
+    const vec3 s1 = rt::cross(d, e1);                                   // CPUScene.cpp:163
+    const float fraction = 1.0f / rt::dot(s1, e0);                      // :166
+    out[(size_t)l * numTris + r] = make_float4(s1.x, s1.y, s1.z, fraction);
+  }
+}
+
 // the model-level boxes are the reference's own (Model::transform's AABB, tested with its exact arithmetic): the caller brings them
 __global__ void k_refit_model_boxes(rtflat_model_node* dst, const rtflat_model_node* src, uint32_t n)
 {

@@ -15,6 +15,14 @@ __device__ __forceinline__ record16 loadRecord(const void* p)
   asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
   return r;
 }
+typedef int record4 __attribute__((ext_vector_type(4)));
+// a 64-byte record and a 16-byte one, issued together, one wait
+__device__ __forceinline__ record16 loadRecordAnd4(const void* p, const void* q, record4& four)
+{
+  record16 r;
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r), "=&s"(four) : "s"(p), "s"(q) : "memory");
+  return r;
+}
 __device__ __forceinline__ float4 recordQuarter(const record16& r, int q)
 {
   return make_float4(__int_as_float(r[4 * q]), __int_as_float(r[4 * q + 1]), __int_as_float(r[4 * q + 2]), __int_as_float(r[4 * q + 3]));
@@ -45,7 +53,6 @@ __device__ __forceinline__ uint64_t laneMaskLe(float a, float b)
 }
 // the seven 16-byte pieces of a FatNode a wave needs: near and far planes per axis (offsets chosen by the direction signs) and the
 // child references; issued together, one wait
-typedef int record4 __attribute__((ext_vector_type(4)));
 struct FatPieces
 {
   record4 nx, fx, ny, fy, nz, fz, ch;
@@ -212,6 +219,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
         float cull = pointPass ? rt::fma(tmx, 1.0f + a.scene.cullRel, a.scene.cullAbs) : FLT_MAX; // boxes beyond a point light hold no accepted triangle
         best = FLT_MAX;
         bestRec = RTFLAT_INVALID;
+        // (wave-uniform) this pass's per-light triangle operands, if the scene has them
+        const float4* operands = (kShadow && !pointPass && a.scene.shadowOperands) ? a.scene.shadowOperands + (size_t)pass * a.scene.numTris : nullptr;
         bool live = valid; // this lane's ray is still looking (an any-hit ray stops at its first accepted triangle)
         uint64_t liveMask = __ballot(live); // the same, wave-wide
 
@@ -260,7 +269,10 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
               const uint32_t first = rtflat_leaf_first(cur), count = rtflat_leaf_count(cur);
               for (uint32_t k = 0; k < count; ++k)
               {
-                const record16 tr = loadRecord(tris4 + (size_t)(first + k) * 4);
+                // shadow rays toward a directional light: cross(d, e1) and 1 / dot(., e0) of the reference's test are the same for
+                // every ray of the scene and come with the record (DeviceScene::shadowOperands): a third of the test's instructions
+                record4 pre{0, 0, 0, 0};
+                const record16 tr = operands ? loadRecordAnd4(tris4 + (size_t)(first + k) * 4, operands + first + k, pre) : loadRecord(tris4 + (size_t)(first + k) * 4);
                 if (COUNT)
                   nFetched++;
                 const float4 a0 = recordQuarter(tr, 0), a1 = recordQuarter(tr, 1), a2 = recordQuarter(tr, 2);
@@ -269,7 +281,9 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packet(TraceArgs a)
                   if (COUNT)
                     nTris++;
                   float t;
-                  const int acc = rtd::triangleTest(vec3{a0.x, a0.y, a0.z}, vec3{a0.w, a1.x, a1.y}, vec3{a1.z, a1.w, a2.x}, o, d, tmn, tmx, t);
+                  const int acc = operands ? rtd::triangleTestWith(vec3{a0.x, a0.y, a0.z}, vec3{a0.w, a1.x, a1.y}, vec3{a1.z, a1.w, a2.x}, o, d,
+                                                                   vec3{__int_as_float(pre[0]), __int_as_float(pre[1]), __int_as_float(pre[2])}, __int_as_float(pre[3]), tmn, tmx, t)
+                                           : rtd::triangleTest(vec3{a0.x, a0.y, a0.z}, vec3{a0.w, a1.x, a1.y}, vec3{a1.z, a1.w, a2.x}, o, d, tmn, tmx, t);
                   if (acc == 2)
                     atomicAdd(&a.counters->nonFinite, 1ull);
                   if (acc == 1)

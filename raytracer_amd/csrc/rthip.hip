@@ -160,6 +160,8 @@ struct rthip_ctx
   DevBuf<rtflat_node> nodes;
   DevBuf<rtflat_tri> tris;
   DevBuf<FatNode> fatNodes;      // the packet kernel's copy of `nodes` (k_fatten), rebuilt whenever the nodes change
+  DevBuf<float4> shadowOperands; // the packet kernel's per-light triangle operands (k_shadow_operands), rebuilt with the fat nodes
+  bool useOperands = true;       // (RTHIP_SHADOW_OPERANDS=0: the packet kernel computes them per ray, the A/B baseline)
   bool useFat = true;            // (RTHIP_FAT=0: the packet kernel decodes the 64-byte records, the A/B baseline)
   DevBuf<Lights> lights;
   DevBuf<rthip_point_light> pointLights;
@@ -347,6 +349,8 @@ DeviceScene devScene(const rthip_ctx* c)
   s.nodes = c->nodes.p;
   s.tris = c->tris.p;
   s.fat = (c->useFat && c->fatNodes.n >= c->info.numNodes) ? c->fatNodes.p : nullptr;
+  s.numTris = c->info.numTris;
+  s.shadowOperands = (c->useOperands && c->hostLights.numDir && c->shadowOperands.n >= (size_t)c->hostLights.numDir * c->info.numTris) ? c->shadowOperands.p : nullptr;
   s.numModelNodes = c->info.numModelNodes;
   s.cullRel = c->info.cullRel;
   s.cullAbs = c->info.cullAbs;
@@ -550,12 +554,24 @@ int fattenNodes(rthip_ctx* c)
   if (!c->useFat || !packetsPossible(c) || c->info.numNodes == 0)
   {
     c->fatNodes.release();
+    c->shadowOperands.release();
     return 0;
   }
   if (int rc = c->fatNodes.ensure(c->info.numNodes))
     return rc;
   hipLaunchKernelGGL(k_fatten, dim3((c->info.numNodes + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->nodes.p, c->info.numNodes, c->fatNodes.p);
   HIPCHK(hipGetLastError());
+  // ... and its per-light triangle operands, for up to four directional lights (16 bytes per light and record)
+  if (c->useOperands && c->hostLights.numDir >= 1 && c->hostLights.numDir <= 4 && c->info.numTris)
+  {
+    if (int rc = c->shadowOperands.ensure((size_t)c->hostLights.numDir * c->info.numTris))
+      return rc;
+    hipLaunchKernelGGL(k_shadow_operands, dim3((c->info.numTris + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->tris.p, c->info.numTris, c->lights.p,
+                       c->hostLights.numDir, c->shadowOperands.p);
+    HIPCHK(hipGetLastError());
+  }
+  else
+    c->shadowOperands.release();
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1073,6 +1089,8 @@ static int createContext(rthip_ctx* c, int device)
     c->buildTraversalCost = (float)std::max(0.0, atof(t));
   if (const char* t = getenv("RTHIP_PLOC_RADIUS"))
     c->plocRadius = (uint32_t)std::max(1, std::min((int)kPlocMaxRadius, atoi(t)));
+  if (const char* t = getenv("RTHIP_SHADOW_OPERANDS"))
+    c->useOperands = atoi(t) != 0;
   if (const char* t = getenv("RTHIP_FAT"))
     c->useFat = atoi(t) != 0;
   if (const char* t = getenv("RTHIP_NO_SPLIT"))
