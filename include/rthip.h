@@ -56,7 +56,11 @@ typedef struct rthip_frame_desc
   uint32_t maxDepth;                  /* path depth cap; the reference hard-codes 12 (src/cpu/CPUScene.cpp:15) */
   uint32_t aovDepths;                 /* record hit-id / shadow AOVs for this many depths of each pass (0 = off) */
   uint32_t tileSize;                  /* square tile edge in pixels (a power of two >= 8); 0 = default 64 */
-  uint32_t numTiles;                  /* tiles this context renders; 0 = the whole image */
+  uint32_t numTiles;                  /* tiles this context renders; 0 = the whole image (every tile: the even tile rows top to bottom,
+                                         then the odd ones).  The list's order is the order of the tiles' pixel blocks in the tile-major
+                                         accumulator (rthip_get_local_tiles reports it), and a frame cut into batches takes contiguous
+                                         runs of it: order an explicit list so that its halves cost about the same (hf10m: the upper
+                                         and the lower image half as the two batches cost 4 % of the frame against interleaved rows) */
   uint32_t pad;
   const uint32_t* tileIds;            /* numTiles tile indices (row-major over ceil(W/ts) x ceil(H/ts)); NULL with numTiles 0 */
 } rthip_frame_desc;

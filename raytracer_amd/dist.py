@@ -87,7 +87,17 @@ def assign_tiles(width, height, world_size, tile_size=64):
     to different GPUs, so every rank sees a similar mix of cheap and expensive image regions."""
     tx, ty = tile_grid(width, height, tile_size)
     ids = np.arange(tx * ty, dtype=np.uint32)
-    return [ids[r::world_size].copy() for r in range(world_size)]
+    return [balanced_order(ids[r::world_size], tx) for r in range(world_size)]
+
+
+def balanced_order(tile_ids, tiles_x):
+    """A rank's tiles with those of the even tile rows first, then those of the odd rows (row-major inside each group).  The
+    kernel library cuts a frame's tile list into contiguous batches; in plain row-major order a two-batch frame is the upper and
+    the lower part of the image, which cost very different amounts under a horizon -- interleaved rows halve any image evenly
+    (the library's own default list is ordered the same way, raytracer_amd/csrc/rthip.hip rthip_begin)."""
+    t = np.asarray(tile_ids, dtype=np.uint32)
+    odd = ((t // np.uint32(tiles_x)) & np.uint32(1)).astype(bool)
+    return np.ascontiguousarray(np.concatenate([t[~odd], t[odd]]), dtype=np.uint32)
 
 
 def padded_tile_count(assignment):
