@@ -851,8 +851,12 @@ int calibrateRefill(rthip_ctx* c)
     return 0;
   }
   const bool sideBySide = both && 2ull * tiles <= c->geom.numLocalTiles; // else both slots trace the same tiles
-  const uint32_t span = sideBySide ? 2 * tiles : tiles;
-  const uint32_t first = (c->geom.numLocalTiles - span) / 2, second = sideBySide ? first + tiles : first;
+  // where in the tile list: one sample from the middle of its first half, the other from the middle of its second half -- a frame's
+  // batches are runs of the list, so these are what the two slots will see (the default list is the even tile rows, then the odd
+  // ones: both samples lie around the image centre; the middle of THAT list is where the bottom rows meet the top rows)
+  const uint32_t nTiles = c->geom.numLocalTiles;
+  const uint32_t first = sideBySide ? nTiles / 4 - std::min(nTiles / 4, tiles / 2) : (nTiles - tiles) / 2;
+  const uint32_t second = sideBySide ? std::min(nTiles - tiles, std::max(first + tiles, nTiles / 2 + nTiles / 4 - std::min(nTiles / 4, tiles / 2))) : first;
   const uint32_t keepBegin = c->lastBatchBegin, keepCount = c->lastBatchCount, keepSamp = c->lastSamp;
   const bool keepRendered = c->renderedAny, keepTiming = c->kernelTiming;
   c->kernelTiming = false;
